@@ -1,0 +1,153 @@
+/* polypmae.h -- C-ABI of the MI355X (gfx950) hot path for SSL4POLYP's MAE pre-train /
+ * ViT-B/16 fine-tune step.
+ *
+ * The reference (irconde/SSL4POLYP) has no FFI of its own: its hot path is the torch/timm op
+ * sequence inside MaskedAutoencoderViT.forward (src/ssl4polyp/models/mae/models_mae.py:150-220),
+ * ViT_from_MAE.forward / VisionTransformer_from_Any.forward (src/ssl4polyp/models/models.py:117-140,
+ * 196-222) and autograd's backward of them (train_classification.py:4531-4533,
+ * mae/engine_pretrain.py:52-65).  Each entry point below names the reference op(s) it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller; the library never
+ *     allocates, frees, retains pointers or synchronises; every launch goes to `stream`
+ *     (a hipStream_t passed as void*).
+ *   - return 0 on success, negative pm_status otherwise; no C++ exceptions cross the ABI.
+ *   - dtype codes: PM_F32 = 0, PM_BF16 = 1.  "act" tensors (activations between kernels) use the
+ *     precision mode's activation type: bf16 in PM_BF16 mode, f32 in PM_F32 mode.
+ *   - matrices are row-major with explicit leading dimensions in ELEMENTS.
+ */
+#ifndef POLYPMAE_H
+#define POLYPMAE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum pm_status { PM_OK = 0, PM_EINVAL = -1, PM_ESHAPE = -2, PM_EARCH = -3, PM_ELAUNCH = -4, PM_EALIGN = -5 };
+enum pm_dtype { PM_F32 = 0, PM_BF16 = 1 };
+
+/* epilogue selector of pm_gemm (what happens to acc = op(A)*op(B) before it is stored) */
+enum pm_epilogue {
+  PM_EPI_STORE = 0,      /* C = acc (+bias)                                          (any Linear) */
+  PM_EPI_GELU = 1,       /* aux = acc+bias (pre-activation), C = gelu_erf(acc+bias)  (timm Mlp.fc1 + act) */
+  PM_EPI_RESIDUAL = 2,   /* C_f32 = resid_f32 + acc + bias                           (Block residual adds) */
+  PM_EPI_DGELU = 3,      /* C = acc * gelu_erf'(aux)                                 (backward of Mlp.act) */
+  PM_EPI_ACCUM = 4       /* C_f32 += acc                                             (grad accumulation) */
+};
+
+const char* pm_strerror(int status);
+int pm_abi_version(void);
+
+/* LayerNorm(eps) over the last dim -- replaces nn.LayerNorm in timm Block.norm1/norm2,
+ * MaskedAutoencoderViT.norm / decoder_norm (models_mae.py:42,57,168,188).
+ * x: f32 [M, D] with row stride ldx; y: out_dtype [M, D] contiguous; mean/rstd: f32 [M] (saved for backward). */
+int pm_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y, int out_dtype,
+                     float* mean, float* rstd, int M, int D, float eps, void* stream);
+
+/* Backward of the above fused with the residual-gradient add of the pre-LN block
+ * (x_out = x + f(LN(x)) => dx = dres + LN'(dy)):
+ *   dx_f32[M,D] (ld ldx) = (dres ? dres : 0) + LN_bwd(dy);  dx_act (optional) = cast(dx_f32)
+ *   dgamma += sum_m dy*xhat ; dbeta += sum_m dy ; dcolsum (optional) += sum_m dx   (bias grad of the
+ *   Linear whose output was added into this residual stream).  The three accumulators must be
+ *   zero-initialised (or hold the running gradient) by the caller. */
+int pm_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma, const float* mean,
+                     const float* rstd, const float* dres, long lddres, float* dx, long lddx, void* dx_act,
+                     int act_dtype, float* dgamma, float* dbeta, float* dcolsum, int M, int D, void* stream);
+
+/* General matrix product with fused epilogue -- replaces every nn.Linear / Conv2d-as-GEMM of the path
+ * and their dgrad / wgrad.   acc[M,N] = sum_k A(m,k) * B(n,k)
+ *   a_kmajor = 0: A stored [M][K] (lda);  1: A stored [K][M] (lda)   (wgrad: A = dY^T)
+ *   b_kmajor = 0: B stored [N][K] (ldb);  1: B stored [K][N] (ldb)   (dgrad: B = W as stored; wgrad: B = X)
+ * in_dtype: element type of A and B (PM_BF16 -> v_mfma_f32_32x32x16_bf16, PM_F32 -> v_mfma_f32_32x32x2_f32).
+ * bias: f32 [N] or NULL.  C: c_dtype [M][N] (ldc).  aux: in_dtype [M][N] (ldc) for GELU / DGELU.
+ * resid: f32 [M][N] (ldc) for PM_EPI_RESIDUAL (may alias C). */
+int pm_gemm(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
+            const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
+            int M, int N, int K, void* stream);
+
+/* Fused multi-head self-attention core -- replaces timm Attention.forward between qkv and proj:
+ * softmax(q k^T * dh^-0.5) v, never materialising the [N,N] scores in HBM.
+ * qkv: act [B, N, 3, H, dh] (the qkv Linear's output as stored); out: act [B, N, H*dh];
+ * lse: f32 [B, H, N] (log-sum-exp of the scaled scores, saved for backward).
+ * Supported: dh in {32, 64}, N <= 224. */
+int pm_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, int dtype, void* stream);
+/* Backward: dqkv [B,N,3,H,dh] from dout [B,N,H*dh]; delta: f32 workspace [B,H,N]. */
+int pm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                     int B, int N, int H, int dh, int dtype, void* stream);
+
+/* Column sums of a [M,N] act matrix into f32 [N] (+=) -- bias gradients of qkv / fc1 / decoder Linears. */
+int pm_colsum(const void* x, long ldx, int dtype, float* out, int M, int N, void* stream);
+
+/* Patch extraction (the im2col of timm PatchEmbed's Conv2d k=s=p), optionally only the kept patches
+ * of MAE random masking (models_mae.py:141-142 applied BEFORE the projection, which is the same
+ * linear map per patch): imgs f32 [B,C,Himg,Himg] NCHW -> cols act [B*keep, C*p*p] in (c,py,px) order.
+ * ids_keep: int32 [B, keep] patch indices, or NULL for all patches in raster order (keep = L). */
+int pm_patch_im2col(const float* imgs, const int* ids_keep, void* cols, int out_dtype, int B, int C, int img,
+                    int p, int keep, void* stream);
+
+/* Token assembly: x[b,0,:] = cls + pos[0]; x[b,1+j,:] = emb[b*keep+j,:] + pos[1+id(b,j),:]
+ * (models_mae.py:155-163; models.py:198-201 / 28-33).  emb f32 [B*keep, D]; x f32 [B, 1+keep, D]. */
+int pm_assemble_tokens(const float* emb, const float* cls, const float* pos, const int* ids_keep, float* x,
+                       int B, int keep, int D, void* stream);
+/* Backward: demb[b*keep+j] = dx[b,1+j]; dcls += sum_b dx[b,0]; dpos (optional, learnable pos_embed)
+ * += scatter of dx.  demb act-typed [B*keep, D]. */
+int pm_assemble_tokens_bwd(const float* dx, const int* ids_keep, void* demb, int act_dtype, float* dcls, float* dpos,
+                           int B, int keep, int D, void* stream);
+
+/* MAE random masking from noise (models_mae.py:123-148): stable ascending argsort per sample.
+ * noise f32 [B,L]; ids_shuffle/ids_restore int32 [B,L]; mask f32 [B,L] (1 = removed). L <= 1024. */
+int pm_mae_masking(const float* noise, int* ids_shuffle, int* ids_restore, float* mask, int B, int L, int len_keep,
+                   void* stream);
+
+/* MAE decoder input (models_mae.py:177-183): mask-token fill + unshuffle + cls re-attach + pos add.
+ * emb f32 [B, 1+keep, D]; out f32 [B, 1+L, D]. */
+int pm_mae_unshuffle(const float* emb, const float* mask_token, const float* dpos, const int* ids_restore, float* out,
+                     int B, int L, int keep, int D, void* stream);
+/* Backward: demb act-typed [B,1+keep,D] (pure gather through ids_shuffle); dmask_token f32 [D] (+=). */
+int pm_mae_unshuffle_bwd(const float* dout, const int* ids_shuffle, void* demb, int act_dtype, float* dmask_token,
+                         int B, int L, int keep, int D, void* stream);
+
+/* MAE reconstruction loss (models_mae.py:95-107,198-214): fused patchify + (optional norm_pix) + per-patch MSE.
+ * pred f32 rows of `ldp` elements; row (b*(L+1)+1+l) holds patch l of sample b when has_cls_row=1 (the
+ * decoder_pred output incl. the cls row), row b*L+l otherwise.  patch_loss f32 [B*L] = mean((pred-target)^2, -1).
+ * pm_mae_loss_finish reduces deterministically (single block): sums = {sum(loss*mask), sum(mask)},
+ * loss = sums[0]/sums[1]  (models_mae.py:213). */
+int pm_mae_loss_fwd(const float* imgs, const float* pred, long ldp, int has_cls_row, float* patch_loss, int B, int C,
+                    int img, int p, int norm_pix, void* stream);
+int pm_mae_loss_finish(const float* patch_loss, const float* mask, long n, float* sums, float* loss, void* stream);
+/* Backward: dpred act-typed [B*(L+has_cls_row), p*p*C] contiguous, same row order as pred (cls rows and kept
+ * patches zeroed); dloss f32 scalar on device. */
+int pm_mae_loss_bwd(const float* imgs, const float* pred, long ldp, int has_cls_row, const float* mask,
+                    const float* sums, const float* dloss, void* dpred, int act_dtype, int B, int C, int img, int p,
+                    int norm_pix, void* stream);
+
+/* f32 -> act cast (weight shadow copies for the bf16 MFMA path). */
+int pm_cast(const float* src, void* dst, int dst_dtype, long n, void* stream);
+
+/* Classifier head on the cls rows (models.py:209,216-221 + tc.py:3347-3374): final LayerNorm of row 0 of each
+ * sample, Linear(D -> n_class) in f32.  x f32 [B, N, D]. */
+int pm_cls_head_fwd(const float* x, int N, const float* gamma, const float* beta, const float* W, const float* bias,
+                    float* xn, float* mean, float* rstd, float* logits, int B, int D, int n_class, float eps,
+                    void* stream);
+/* Backward: dx f32 [B,N,D] fully written (zeros except row 0; NULL = frozen backbone, not needed);
+ * dW/dbias/dgamma/dbeta (+=). */
+int pm_cls_head_bwd(const float* dlogits, const float* x, int N, const float* gamma, const float* W, const float* xn,
+                    const float* mean, const float* rstd, float* dx, void* dx_act, int act_dtype, float* dW,
+                    float* dbias, float* dgamma, float* dbeta, int B, int D, int n_class, void* stream);
+
+/* Fused multi-tensor AdamW over one flat f32 parameter range (torch.optim.AdamW semantics,
+ * tc.py:5766-5768 / main_pretrain.py:218) that also refreshes the act-typed shadow copy used by the GEMMs.
+ * grad_scale multiplies the gradient (1/world, 1/accum).  step >= 1. */
+int pm_adamw(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long n, float lr,
+             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* One-pass gradient statistics over a flat f32 range: out[0] += sum(g^2), out[1] += #NaN, out[2] += #Inf
+ * (the device-side counterpart of tc.py:1437-1454 _compute_grad_norm and misc.py:387-400 detect_grad_anomalies). */
+int pm_grad_stats(const float* g, long n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -52,8 +52,8 @@ class ViTConfig:
 
 VIT_BASE = ViTConfig()
 # Small geometry used by the committed fixtures (weights travel in the fixture).
-VIT_TINY = ViTConfig(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=4,
-                     decoder_embed_dim=32, decoder_depth=1, decoder_num_heads=4)
+VIT_TINY = ViTConfig(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2,
+                     decoder_embed_dim=32, decoder_depth=1, decoder_num_heads=1)
 
 
 # --------------------------------------------------------------------------

@@ -1,0 +1,85 @@
+"""ctypes binding of the C-ABI library (include/polypmae.h).
+
+The product path has NO CPU or eager fallback: if the HIP library is missing or a call
+fails, this module raises.  Tensors cross the boundary as raw device pointers + sizes.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
+
+PM_F32, PM_BF16 = 0, 1
+EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ACCUM = 0, 1, 2, 3, 4
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpolypmae.so")
+
+P, I, L, F = c_void_p, c_int, c_long, c_float
+
+# name -> argtypes, exactly the prototypes of include/polypmae.h
+SIGNATURES = {
+    "pm_layernorm_fwd": [P, L, P, P, P, I, P, P, I, I, F, P],
+    "pm_layernorm_bwd": [P, I, P, L, P, P, P, P, L, P, L, P, I, P, P, P, I, I, P],
+    "pm_gemm": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P],
+    "pm_attention_fwd": [P, P, P, I, I, I, I, I, P],
+    "pm_attention_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
+    "pm_colsum": [P, L, I, P, I, I, P],
+    "pm_patch_im2col": [P, P, P, I, I, I, I, I, I, P],
+    "pm_assemble_tokens": [P, P, P, P, P, I, I, I, P],
+    "pm_assemble_tokens_bwd": [P, P, P, I, P, P, I, I, I, P],
+    "pm_mae_masking": [P, P, P, P, I, I, I, P],
+    "pm_mae_unshuffle": [P, P, P, P, P, I, I, I, I, P],
+    "pm_mae_unshuffle_bwd": [P, P, P, I, P, I, I, I, I, P],
+    "pm_mae_loss_fwd": [P, P, L, I, P, I, I, I, I, I, P],
+    "pm_mae_loss_finish": [P, P, L, P, P, P],
+    "pm_mae_loss_bwd": [P, P, L, I, P, P, P, P, I, I, I, I, I, I, P],
+    "pm_cast": [P, P, I, L, P],
+    "pm_cls_head_fwd": [P, I, P, P, P, P, P, P, P, P, I, I, I, F, P],
+    "pm_cls_head_bwd": [P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, I, I, I, P],
+    "pm_adamw": [P, P, P, P, P, I, L, F, F, F, F, F, I, F, P],
+    "pm_grad_stats": [P, L, P, P],
+}
+
+_lib = None
+
+
+class PolypMaeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpolypmae.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PolypMaeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU/eager fallback for the MI355X hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.pm_strerror.restype = c_char_p
+    lib.pm_strerror.argtypes = [c_int]
+    lib.pm_abi_version.restype = c_int
+    lib.pm_abi_version.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise PolypMaeError(f"{what} failed: {load().pm_strerror(status).decode()} (status {status})")
+
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+
+    if torch_dtype == torch.float32:
+        return PM_F32
+    if torch_dtype == torch.bfloat16:
+        return PM_BF16
+    raise PolypMaeError(f"unsupported dtype {torch_dtype}")

@@ -1,0 +1,426 @@
+// pm_attention.hip -- fused multi-head self-attention core, forward and backward, for the short
+// sequences of ViT-B/16 (N = 197, or 50 under MAE masking) and its MAE decoder (N = 197, dh = 32).
+// Replaces timm 0.4.12 Attention.forward between the qkv and proj Linears
+//   q,k,v = qkv.reshape(B,N,3,H,dh).permute(2,0,3,1,4); softmax(q k^T * dh^-0.5) v; transpose(1,2).reshape(B,N,C)
+// (used by reference models_mae.py:39-41,53-55 through timm Block) and its autograd backward.
+//
+// MI355X design: a whole (batch, head) problem fits one CU -- K and V (or Q and dO) of the head are staged
+// once into LDS (<= 2 x 224 x 64 bf16 = 56 KiB), scores / probabilities live only in MFMA accumulators, the
+// [N,N] matrix never reaches HBM.  All contractions are v_mfma_f32_32x32x16_bf16 (f32 mode:
+// v_mfma_f32_32x32x2_f32); products are oriented so that the reduction index of the NEXT product sits
+// in the accumulator's register dimension, which lets the accumulator be fed back as the MFMA B operand
+// with no LDS round trip ("accumulator as operand"):
+//   fwd   : S^T[key][q] = K Q^T   (lane = q)  -> softmax over registers (+1 cross-half shuffle)
+//           O^T[d][q]  += V^T[d][key] P^T[key][q]          (V^T fragments by ds_read_b64_tr_b16)
+//   bwd_q : S^T, dP^T[key][q] = V dO^T (lane = q) -> dS^T -> dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+//   bwd_kv: S[q][key] = Q K^T, dP[q][key] = dO V^T (lane = key) ->
+//           dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+// Every output tile therefore has (q or key) on the lane and 4 consecutive d per register quad: stores
+// are 8-B (bf16) / 16-B (f32) vectors into the [B,N,(3,)H,dh] activations, the head transpose is free.
+// S and dP are recomputed in both backward kernels (7 products instead of 5) to avoid any cross-wave
+// reduction or atomics.  Roofline: MFMA-bound; algorithmic FLOPs fwd 4*N^2*dh per head, bwd 10*N^2*dh.
+#include "pm_common.h"
+
+namespace {
+
+template <int RB> __device__ __forceinline__ int swz(int row) {
+  // XOR applied to the 16-B chunk index of LDS row `row` (row = RB bytes).  Chosen so that BOTH the
+  // ds_read_b128 row reads of the 32x32x16 operand map and the ds_read_b64_tr_b16 transposed reads
+  // (4 consecutive rows per 16-lane group) are bank-conflict free.
+  if constexpr (RB == 64) return (row >> 2) & 3;
+  else if constexpr (RB == 128) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+  else return row & 15;
+}
+
+// Stage `rows_valid` rows of DH elements (global row stride `ld` elements) into an LDS image of `rows_total`
+// rows; rows beyond rows_valid are zero filled.
+template <typename T, int DH>
+__device__ __forceinline__ void load_image(char* img, const T* __restrict__ src, long ld, int rows_valid,
+                                           int rows_total, int tid, int nthreads) {
+  constexpr int RB = DH * sizeof(T);
+  constexpr int CPR = RB / 16;
+  constexpr int EPC = 16 / sizeof(T);
+  for (int id = tid; id < rows_total * CPR; id += nthreads) {
+    const int row = id / CPR, c = id % CPR;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < rows_valid) v = *reinterpret_cast<const u32x4*>(src + (long)row * ld + c * EPC);
+    *reinterpret_cast<u32x4*>(img + row * RB + 16 * (c ^ swz<RB>(row))) = v;
+  }
+}
+
+// Row-read fragment: rows rb..rb+31 on lanes (l&31), k-step kk (chunk 2*kk + h).
+template <typename T, int DH>
+__device__ __forceinline__ Frag16 frag_rows(const char* img, int rb, int kk, int lane) {
+  constexpr int RB = DH * sizeof(T);
+  const int row = rb + (lane & 31);
+  const int c = 2 * kk + (lane >> 5);
+  Frag16 f;
+  f.u = *reinterpret_cast<const u32x4*>(img + row * RB + 16 * (c ^ swz<RB>(row)));
+  return f;
+}
+
+// Fragment straight from global memory (B operand: lane (r,h) holds elements of row r).
+template <typename T>
+__device__ __forceinline__ Frag16 frag_global(const T* __restrict__ rowptr, bool valid, int kk, int lane) {
+  constexpr int EPC = 16 / sizeof(T);
+  Frag16 f;
+  f.u = (u32x4){0u, 0u, 0u, 0u};
+  if (valid) f.u = *reinterpret_cast<const u32x4*>(rowptr + (2 * kk + (lane >> 5)) * EPC);
+  return f;
+}
+
+// acc_out[d][lane] += sum over the 32 rows r of X:  Img[rb + r][d0 + d] * X[r][lane]
+// where X is a 32x32 accumulator tile (rows in registers, column on the lane) used as the B operand.
+template <typename T, int DH>
+__device__ __forceinline__ f32x16 mma_imgT_acc(const char* img, int rb, int d0, const f32x16& x, f32x16 acc, int lane) {
+  constexpr int RB = DH * sizeof(T);
+  if constexpr (sizeof(T) == 2) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, hh = g >> 1;
+    const int col = d0 + 16 * (g & 1) + 4 * p;
+    const int c = col >> 3, sub = 8 * (p & 1);
+    using lds_s4 = __attribute__((address_space(3))) short4v;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag16 a, b;
+      const int r0 = rb + 16 * s + 4 * hh + q;
+      const int r1 = r0 + 8;
+      const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(img + r0 * RB + 16 * (c ^ swz<RB>(r0)) + sub));
+      const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(img + r1 * RB + 16 * (c ^ swz<RB>(r1)) + sub));
+      a.u[0] = ((unsigned)(unsigned short)lo[0]) | (((unsigned)(unsigned short)lo[1]) << 16);
+      a.u[1] = ((unsigned)(unsigned short)lo[2]) | (((unsigned)(unsigned short)lo[3]) << 16);
+      a.u[2] = ((unsigned)(unsigned short)hi[0]) | (((unsigned)(unsigned short)hi[1]) << 16);
+      a.u[3] = ((unsigned)(unsigned short)hi[2]) | (((unsigned)(unsigned short)hi[3]) << 16);
+      // element j of lane half hh  <->  row 16s + 8(j>>2) + 4hh + (j&3) of X  ==  registers 8s..8s+7 in order
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b.h[j] = (__bf16)x[8 * s + j];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+    }
+  } else {
+    const int hh = lane >> 5;
+    const int col = d0 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rb + acc_row(r, hh);
+      const float a = *reinterpret_cast<const float*>(img + row * RB + 16 * ((col >> 2) ^ swz<RB>(row)) + 4 * (col & 3));
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[r], acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// Store an accumulator tile whose lane is a token row and whose registers are 32 consecutive features.
+template <typename T>
+__device__ __forceinline__ void store_tile_T(T* __restrict__ rowptr, bool valid, const f32x16& acc, float scale, int lane) {
+  if (!valid) return;
+  const int hh = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v = {acc[4 * g] * scale, acc[4 * g + 1] * scale, acc[4 * g + 2] * scale, acc[4 * g + 3] * scale};
+    store4<T>(rowptr + 8 * g + 4 * hh, v);
+  }
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+template <int NT> struct Waves { static constexpr int value = NT >= 4 ? 4 : NT; };
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DH, int NT>
+__global__ __launch_bounds__(Waves<NT>::value * 64) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                                        float* __restrict__ lse, int N, int H,
+                                                                        float scale) {
+  constexpr int RB = DH * sizeof(T);
+  constexpr int KS = RB / 32;   // 16-B fragment pairs along the head dim
+  constexpr int DT = DH / 32;   // 32-wide output tiles along the head dim
+  constexpr int NW = Waves<NT>::value;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* imgK = smem;
+  char* imgV = smem + NT * 32 * RB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * DH;
+  const T* base = qkv + (long)b * N * ld + h * DH;
+  load_image<T, DH>(imgK, base + H * DH, ld, N, NT * 32, tid, NW * 64);
+  load_image<T, DH>(imgV, base + 2 * H * DH, ld, N, NT * 32, tid, NW * 64);
+  __syncthreads();
+  const float c = scale * kLog2e;
+  for (int qt = wave; qt < NT; qt += NW) {
+    const int q = qt * 32 + (lane & 31);
+    const bool qv = q < N;
+    Frag16 fq[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) fq[kk] = frag_global<T>(base + (long)q * ld, qv, kk, lane);
+    f32x16 s[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      s[kt] = zero16();
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) s[kt] = mfma16B<T>(frag_rows<T, DH>(imgK, kt * 32, kk, lane), fq[kk], s[kt]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + acc_row(r, hh);
+        s[kt][r] = key < N ? s[kt][r] : -INFINITY;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[kt][r] = __builtin_amdgcn_exp2f((s[kt][r] - mx) * c);
+        sum += s[kt][r];
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    if (qv && hh == 0) lse[((long)b * H + h) * N + q] = mx * scale + __logf(sum);
+    const float inv = 1.0f / sum;
+    T* orow = out + ((long)b * N + q) * H * DH + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      f32x16 o = zero16();
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) o = mma_imgT_acc<T, DH>(imgV, kt * 32, dt * 32, s[kt], o, lane);
+      store_tile_T<T>(orow + dt * 32, qv, o, inv, lane);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, query side: dQ (and delta = rowsum(dO * O), written for the key-side kernel)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DH, int NT>
+__global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                                          const T* __restrict__ dout,
+                                                                          const float* __restrict__ lse,
+                                                                          float* __restrict__ delta, T* __restrict__ dqkv,
+                                                                          int N, int H, float scale) {
+  constexpr int RB = DH * sizeof(T);
+  constexpr int KS = RB / 32;
+  constexpr int DT = DH / 32;
+  constexpr int NW = Waves<NT>::value;
+  constexpr int EPC = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* imgK = smem;
+  char* imgV = smem + NT * 32 * RB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * DH, ldo = (long)H * DH;
+  const T* base = qkv + (long)b * N * ld + h * DH;
+  load_image<T, DH>(imgK, base + H * DH, ld, N, NT * 32, tid, NW * 64);
+  load_image<T, DH>(imgV, base + 2 * H * DH, ld, N, NT * 32, tid, NW * 64);
+  __syncthreads();
+  const float c = scale * kLog2e;
+  for (int qt = wave; qt < NT; qt += NW) {
+    const int q = qt * 32 + (lane & 31);
+    const bool qv = q < N;
+    const T* orow = out + ((long)b * N + q) * ldo + h * DH;
+    const T* dorow = dout + ((long)b * N + q) * ldo + h * DH;
+    Frag16 fq[KS], fdo[KS];
+    float dl = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      fq[kk] = frag_global<T>(base + (long)q * ld, qv, kk, lane);
+      fdo[kk] = frag_global<T>(dorow, qv, kk, lane);
+      const Frag16 fo = frag_global<T>(orow, qv, kk, lane);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        if constexpr (sizeof(T) == 2) dl += (float)fdo[kk].h[e] * (float)fo.h[e];
+        else dl += fdo[kk].f[e] * fo.f[e];
+      }
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    const long sidx = ((long)b * H + h) * N + q;
+    if (qv && hh == 0) delta[sidx] = dl;
+    const float l2 = qv ? lse[sidx] * kLog2e : 0.f;
+    f32x16 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        s = mfma16B<T>(frag_rows<T, DH>(imgK, kt * 32, kk, lane), fq[kk], s);
+        dp = mfma16B<T>(frag_rows<T, DH>(imgV, kt * 32, kk, lane), fdo[kk], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + acc_row(r, hh);
+        const float p = (key < N && qv) ? __builtin_amdgcn_exp2f(s[r] * c - l2) : 0.f;
+        s[r] = p * (dp[r] - dl) * scale;  // dS^T
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) dq[dt] = mma_imgT_acc<T, DH>(imgK, kt * 32, dt * 32, s, dq[dt], lane);
+    }
+    T* dqrow = dqkv + ((long)b * N + q) * ld + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) store_tile_T<T>(dqrow + dt * 32, qv, dq[dt], 1.0f, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, key side: dK and dV
+// ------------------------------------------------------------------------------------------------
+template <typename T, int DH, int NT>
+__global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                                           const float* __restrict__ lse,
+                                                                           const float* __restrict__ delta,
+                                                                           T* __restrict__ dqkv, int N, int H, float scale) {
+  constexpr int RB = DH * sizeof(T);
+  constexpr int KS = RB / 32;
+  constexpr int DT = DH / 32;
+  constexpr int NW = Waves<NT>::value;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* imgQ = smem;
+  char* imgDO = smem + NT * 32 * RB;
+  float* sl2 = reinterpret_cast<float*>(smem + 2 * NT * 32 * RB);  // lse * log2e per query
+  float* sdl = sl2 + NT * 32;                                      // delta per query
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const long ld = 3L * H * DH, ldo = (long)H * DH;
+  const T* base = qkv + (long)b * N * ld + h * DH;
+  load_image<T, DH>(imgQ, base, ld, N, NT * 32, tid, NW * 64);
+  load_image<T, DH>(imgDO, dout + (long)b * N * ldo + h * DH, ldo, N, NT * 32, tid, NW * 64);
+  for (int i = tid; i < NT * 32; i += NW * 64) {
+    const long sidx = ((long)b * H + h) * N + i;
+    sl2[i] = i < N ? lse[sidx] * kLog2e : 0.f;
+    sdl[i] = i < N ? delta[sidx] : 0.f;
+  }
+  __syncthreads();
+  const float c = scale * kLog2e;
+  for (int kt = wave; kt < NT; kt += NW) {
+    const int key = kt * 32 + (lane & 31);
+    const bool kv = key < N;
+    Frag16 fk[KS], fv[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      fk[kk] = frag_global<T>(base + (long)key * ld + H * DH, kv, kk, lane);
+      fv[kk] = frag_global<T>(base + (long)key * ld + 2 * H * DH, kv, kk, lane);
+    }
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      dk[dt] = zero16();
+      dv[dt] = zero16();
+    }
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        s = mfma16B<T>(frag_rows<T, DH>(imgQ, qt * 32, kk, lane), fk[kk], s);
+        dp = mfma16B<T>(frag_rows<T, DH>(imgDO, qt * 32, kk, lane), fv[kk], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qt * 32 + acc_row(r, hh);
+        const float p = (q < N && kv) ? __builtin_amdgcn_exp2f(s[r] * c - sl2[q]) : 0.f;
+        s[r] = p;                                // P
+        dp[r] = p * (dp[r] - sdl[q]) * scale;    // dS
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        dv[dt] = mma_imgT_acc<T, DH>(imgDO, qt * 32, dt * 32, s, dv[dt], lane);
+        dk[dt] = mma_imgT_acc<T, DH>(imgQ, qt * 32, dt * 32, dp, dk[dt], lane);
+      }
+    }
+    T* drow = dqkv + ((long)b * N + key) * ld + h * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      store_tile_T<T>(drow + H * DH + dt * 32, kv, dk[dt], 1.0f, lane);
+      store_tile_T<T>(drow + 2 * H * DH + dt * 32, kv, dv[dt], 1.0f, lane);
+    }
+  }
+}
+
+template <typename T, int DH, int NT>
+int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t s) {
+  constexpr int NW = Waves<NT>::value;
+  const size_t lds = 2 * NT * 32 * DH * sizeof(T);
+  const float scale = 1.0f / sqrtf((float)DH);
+  auto kern = attn_fwd_kernel<T, DH, NT>;
+  if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(NW * 64), lds, s, (const T*)qkv, (T*)out, lse, N, H, scale);
+  return pm_check_launch();
+}
+
+template <typename T, int DH, int NT>
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+               int N, int H, hipStream_t s) {
+  constexpr int NW = Waves<NT>::value;
+  const size_t lds = 2 * NT * 32 * DH * sizeof(T);
+  const size_t lds_kv = lds + 2 * NT * 32 * sizeof(float);
+  const float scale = 1.0f / sqrtf((float)DH);
+  auto kq = attn_bwd_q_kernel<T, DH, NT>;
+  auto kkv = attn_bwd_kv_kernel<T, DH, NT>;
+  if (lds > 65536) (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds_kv > 65536) (void)hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+  hipLaunchKernelGGL(kq, dim3(B * H), dim3(NW * 64), lds, s, (const T*)qkv, (const T*)out, (const T*)dout, lse, delta,
+                     (T*)dqkv, N, H, scale);
+  hipLaunchKernelGGL(kkv, dim3(B * H), dim3(NW * 64), lds_kv, s, (const T*)qkv, (const T*)dout, lse,
+                     (const float*)delta, (T*)dqkv, N, H, scale);
+  return pm_check_launch();
+}
+
+template <typename T, int DH>
+int dispatch_fwd(int nt, const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t s) {
+  if (nt <= 1) return launch_fwd<T, DH, 1>(qkv, out, lse, B, N, H, s);
+  if (nt <= 2) return launch_fwd<T, DH, 2>(qkv, out, lse, B, N, H, s);
+  return launch_fwd<T, DH, 7>(qkv, out, lse, B, N, H, s);
+}
+template <typename T, int DH>
+int dispatch_bwd(int nt, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                 int B, int N, int H, hipStream_t s) {
+  if (nt <= 1) return launch_bwd<T, DH, 1>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+  if (nt <= 2) return launch_bwd<T, DH, 2>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+  return launch_bwd<T, DH, 7>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+}
+
+inline int check_shape(int B, int N, int H, int dh, int dtype) {
+  if (B <= 0 || N <= 0 || H <= 0) return PM_ESHAPE;
+  if (N > 224) return PM_ESHAPE;
+  if (dh != 32 && dh != 64) return PM_ESHAPE;
+  if (dtype != PM_BF16 && dtype != PM_F32) return PM_EINVAL;
+  return PM_OK;
+}
+
+}  // namespace
+
+extern "C" int pm_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, int dtype,
+                                void* stream) {
+  if (!qkv || !out || !lse) return PM_EINVAL;
+  const int st = check_shape(B, N, H, dh, dtype);
+  if (st) return st;
+  const int nt = (N + 31) / 32;
+  hipStream_t s = pm_stream(stream);
+  if (dtype == PM_BF16)
+    return dh == 64 ? dispatch_fwd<__bf16, 64>(nt, qkv, out, lse, B, N, H, s)
+                    : dispatch_fwd<__bf16, 32>(nt, qkv, out, lse, B, N, H, s);
+  return dh == 64 ? dispatch_fwd<float, 64>(nt, qkv, out, lse, B, N, H, s)
+                  : dispatch_fwd<float, 32>(nt, qkv, out, lse, B, N, H, s);
+}
+
+extern "C" int pm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta,
+                                void* dqkv, int B, int N, int H, int dh, int dtype, void* stream) {
+  if (!qkv || !out || !dout || !lse || !delta || !dqkv) return PM_EINVAL;
+  const int st = check_shape(B, N, H, dh, dtype);
+  if (st) return st;
+  const int nt = (N + 31) / 32;
+  hipStream_t s = pm_stream(stream);
+  if (dtype == PM_BF16)
+    return dh == 64 ? dispatch_bwd<__bf16, 64>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
+                    : dispatch_bwd<__bf16, 32>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+  return dh == 64 ? dispatch_bwd<float, 64>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
+                  : dispatch_bwd<float, 32>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+}

@@ -1,0 +1,104 @@
+// pm_common.h -- shared device helpers for the gfx950 kernels (wave64, MFMA 32x32, bf16/f32 element traits).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/polypmae.h"
+
+#define PM_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// A 16-byte operand fragment: 8 bf16 (one 32x32x16 MFMA) or 4 f32 (four 32x32x2 MFMAs).
+union Frag16 {
+  u32x4 u;
+  bf16x8 h;
+  f32x4 f;
+};
+
+static inline hipStream_t pm_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int pm_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? PM_OK : PM_ELAUNCH;
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<__bf16> {
+  static constexpr int kDtype = PM_BF16;
+  static constexpr int kPer16B = 8;
+};
+template <> struct ElemTraits<float> {
+  static constexpr int kDtype = PM_F32;
+  static constexpr int kPer16B = 4;
+};
+
+// acc[reg -> A-row][lane -> B-col] += A(16B frag) x B(16B frag).
+// bf16: one v_mfma_f32_32x32x16_bf16 (lane (r,h) holds k = 8h..8h+7 of row/col r).
+// f32 : four v_mfma_f32_32x32x2_f32; element e of lane half h stands for k = 4*(2j+h)+e in BOTH
+//       operands, so any k permutation is consistent (exact f32 fma chain).
+template <typename T>
+__device__ __forceinline__ f32x16 mfma16B(const Frag16& a, const Frag16& b, f32x16 acc) {
+  if constexpr (sizeof(T) == 2) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[0], b.f[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[1], b.f[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[2], b.f[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[3], b.f[3], acc, 0, 0, 0);
+    return acc;
+  }
+}
+
+// Row index (within a 32x32 accumulator tile) of register `reg` for lane half `h`.
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// Load / store 4 consecutive elements as f32x4.
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    return *reinterpret_cast<const f32x4*>(p);
+  } else {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+  }
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v) {
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else {
+    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// erf-GELU (timm Mlp act_layer=nn.GELU, exact form) and its derivative.
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}

@@ -1,0 +1,466 @@
+// pm_misc.hip -- the HBM-bound kernels around the GEMMs: patch im2col (+ kept-patch gather), token
+// assembly (cls / pos-embed), bias-gradient column sums, casts, classifier head, fused AdamW.
+// Reference ops replaced are named per kernel.  All are streaming kernels: 16-B vector accesses,
+// one wave64 per token row where a row is the unit, grid capped and grid-strided.
+#include "pm_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// column sums: out[n] += sum_m x[m][n]   (bias gradients)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ldx, float* __restrict__ out, int M, int N) {
+  __shared__ float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 256 + lane * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    for (long m = (long)blockIdx.y * 4 + wave; m < M; m += (long)gridDim.y * 4) acc += load4<T>(x + m * ldx + n);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = acc[e];
+  __syncthreads();
+  const int t = threadIdx.x;
+  const int nn = blockIdx.x * 256 + t;
+  if (nn < N) atomicAdd(out + nn, (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// im2col of the k = s = p patch-embedding conv, optionally gathering only kept patches
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ imgs, const int* __restrict__ ids_keep,
+                                                     T* __restrict__ cols, int C, int img, int p, int keep) {
+  const int b = blockIdx.x / keep, j = blockIdx.x % keep;
+  const int grid = img / p;
+  const int pid = ids_keep ? ids_keep[b * keep + j] : j;
+  const int gy = pid / grid, gx = pid % grid;
+  const int p4 = p >> 2;
+  const int nvec = C * p * p4;
+  const float* src = imgs + (long)b * C * img * img + (long)gy * p * img + gx * p;
+  T* dst = cols + (long)blockIdx.x * C * p * p;
+  for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
+    const int c = v / (p * p4), rem = v % (p * p4);
+    const int py = rem / p4, px = (rem % p4) * 4;
+    const f32x4 val = *reinterpret_cast<const f32x4*>(src + (long)c * img * img + (long)py * img + px);
+    store4<T>(dst + (c * p + py) * p + px, val);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// token assembly (cls + pos-embed) and its backward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ emb, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, const int* __restrict__ ids_keep,
+                                                       float* __restrict__ x, int B, int keep, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long rows = (long)B * (keep + 1);
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const int b = row / (keep + 1), t = row % (keep + 1);
+    const float* src;
+    const float* pp;
+    if (t == 0) {
+      src = cls;
+      pp = pos;
+    } else {
+      const int j = t - 1;
+      const int pid = ids_keep ? ids_keep[b * keep + j] : j;
+      src = emb + ((long)b * keep + j) * D;
+      pp = pos + (long)(1 + pid) * D;
+    }
+    for (int c = lane * 4; c < D; c += 256) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + c);
+      const f32x4 q = *reinterpret_cast<const f32x4*>(pp + c);
+      *reinterpret_cast<f32x4*>(x + row * D + c) = a + q;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, const int* __restrict__ ids_keep,
+                                                           T* __restrict__ demb, float* __restrict__ dpos, int B, int keep,
+                                                           int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long rows = (long)B * keep;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const int b = row / keep, j = row % keep;
+    const float* src = dx + ((long)b * (keep + 1) + 1 + j) * D;
+    const int pid = ids_keep ? ids_keep[b * keep + j] : j;
+    for (int c = lane * 4; c < D; c += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + c);
+      store4<T>(demb + row * D + c, v);
+      if (dpos) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dpos + (long)(1 + pid) * D + c + e, v[e]);
+      }
+    }
+  }
+}
+
+// dcls[d] += sum_b dx[b, 0, d]   (also dpos[0] when the positional table is learnable)
+__global__ __launch_bounds__(256) void cls_grad_kernel(const float* __restrict__ dx, float* __restrict__ dcls,
+                                                       float* __restrict__ dpos0, int B, long sample_stride, int D) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dx[(long)b * sample_stride + d];
+  dcls[d] += s;
+  if (dpos0) dpos0[d] += s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cast
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+  const long nvec = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256)
+    store4<T>(dst + 4 * i, *reinterpret_cast<const f32x4*>(src + 4 * i));
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(nvec << 2) + threadIdx.x] = (T)src[(nvec << 2) + threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+// classifier head: LayerNorm of the cls row + Linear(D -> n_class), f32 throughout
+// ---------------------------------------------------------------------------------------------
+constexpr int kHeadVec = 4;  // D <= 1024
+__global__ __launch_bounds__(64) void cls_head_fwd_kernel(const float* __restrict__ x, long sample_stride,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ W, const float* __restrict__ bias,
+                                                          float* __restrict__ xn, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out, float* __restrict__ logits, int D,
+                                                          int n_class, float eps) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* xr = x + (long)b * sample_stride;
+  const int nvec = D >> 2;
+  f32x4 v[kHeadVec];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kHeadVec; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kHeadVec; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    mean_out[b] = mean;
+    rstd_out[b] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < kHeadVec; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nvec) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + 4 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+      *reinterpret_cast<f32x4*>(xn + (long)b * D + 4 * c) = v[i];
+    }
+  }
+  for (int k = 0; k < n_class; ++k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < kHeadVec; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvec) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)k * D + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += v[i][e] * w[e];
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) logits[(long)b * n_class + k] = acc + (bias ? bias[k] : 0.f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cls_head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ x,
+                                                           int N, const float* __restrict__ gamma,
+                                                           const float* __restrict__ W, const float* __restrict__ xn,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           float* __restrict__ dx, T* __restrict__ dx_act,
+                                                           float* __restrict__ dW, float* __restrict__ dbias,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int D,
+                                                           int n_class) {
+  __shared__ float s_red[2][4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long sample = (long)N * D;
+  const float* xr = x + (long)b * sample;
+  const float mu = mean[b], rs = rstd[b];
+  // each thread owns columns tid, tid+256, ...
+  float s1 = 0.f, s2 = 0.f;
+  for (int d = tid; d < D; d += 256) {
+    float g = 0.f;
+    for (int k = 0; k < n_class; ++k) g += dlogits[(long)b * n_class + k] * W[(long)k * D + d];
+    const float xh = (xr[d] - mu) * rs;
+    const float gg = g * gamma[d];
+    s1 += gg;
+    s2 += gg * xh;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    s_red[0][wave] = s1;
+    s_red[1][wave] = s2;
+  }
+  __syncthreads();
+  const float c1 = ((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3])) / (float)D;
+  const float c2 = ((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3])) / (float)D;
+  for (int d = tid; d < D; d += 256) {
+    float g = 0.f;
+    for (int k = 0; k < n_class; ++k) {
+      const float dl = dlogits[(long)b * n_class + k];
+      g += dl * W[(long)k * D + d];
+      if (dW) atomicAdd(dW + (long)k * D + d, dl * xn[(long)b * D + d]);
+    }
+    const float xh = (xr[d] - mu) * rs;
+    if (dgamma) atomicAdd(dgamma + d, g * xh);
+    if (dbeta) atomicAdd(dbeta + d, g);
+    const float o = rs * (g * gamma[d] - c1 - xh * c2);
+    if (dx) dx[(long)b * sample + d] = o;
+    if (dx_act) dx_act[(long)b * sample + d] = (T)o;
+  }
+  if (dbias && tid < n_class) atomicAdd(dbias + tid, dlogits[(long)b * n_class + tid]);
+  if (!dx) return;  // frozen backbone: nothing below the head needs a gradient
+  // zero the gradient of every non-cls token of this sample
+  const long rest = sample - D;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (long i = tid; i < (rest >> 2); i += 256) {
+    *reinterpret_cast<f32x4*>(dx + (long)b * sample + D + 4 * i) = z;
+    if (dx_act) store4<T>(dx_act + (long)b * sample + D + 4 * i, z);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused AdamW (torch.optim.AdamW update rule) + act-typed shadow refresh
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, T* __restrict__ shadow, long n, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1, float rsqrt_bc2,
+                                                    float gscale) {
+  const long nvec = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    f32x4 pp = *reinterpret_cast<const f32x4*>(p + 4 * i);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * i);
+    f32x4 mm = *reinterpret_cast<const f32x4*>(m + 4 * i);
+    f32x4 vv = *reinterpret_cast<const f32x4*>(v + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gg[e] * gscale;
+      pp[e] *= (1.0f - lr * wd);
+      mm[e] = beta1 * mm[e] + (1.0f - beta1) * gr;
+      vv[e] = beta2 * vv[e] + (1.0f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[e]) * rsqrt_bc2 + eps;
+      pp[e] -= (lr / bc1) * (mm[e] / denom);
+    }
+    *reinterpret_cast<f32x4*>(p + 4 * i) = pp;
+    *reinterpret_cast<f32x4*>(m + 4 * i) = mm;
+    *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+    if (shadow) store4<T>(shadow + 4 * i, pp);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// gradient statistics in one pass: out[0] += sum g^2, out[1] += #NaN, out[2] += #Inf
+// (replaces the per-parameter host-synchronising loops of tc.py:1437-1454 and misc.py:387-400)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+  __shared__ float red[3][4];
+  float ss = 0.f, nn = 0.f, ni = 0.f;
+  const long nvec = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ss += v[e] * v[e];
+      nn += (v[e] != v[e]) ? 1.f : 0.f;
+      ni += (fabsf(v[e]) == INFINITY) ? 1.f : 0.f;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = g[(nvec << 2) + threadIdx.x];
+    ss += v * v;
+    nn += (v != v) ? 1.f : 0.f;
+    ni += (fabsf(v) == INFINITY) ? 1.f : 0.f;
+  }
+  ss = wave_sum(ss);
+  nn = wave_sum(nn);
+  ni = wave_sum(ni);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = ss;
+    red[1][wave] = nn;
+    red[2][wave] = ni;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    atomicAdd(out + k, (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]));
+  }
+}
+
+inline int cap_grid(long work_items, int per_block, int cap) {
+  long g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int pm_colsum(const void* x, long ldx, int dtype, float* out, int M, int N, void* stream) {
+  if (!x || !out) return PM_EINVAL;
+  if (M <= 0 || N <= 0 || (N & 3) || (ldx & 3)) return PM_ESHAPE;
+  const dim3 grid((N + 255) / 256, cap_grid(M, 64, 128));
+  if (dtype == PM_BF16)
+    hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), (const __bf16*)x, ldx, out, M, N);
+  else if (dtype == PM_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, pm_stream(stream), (const float*)x, ldx, out, M, N);
+  else
+    return PM_EINVAL;
+  return pm_check_launch();
+}
+
+extern "C" int pm_patch_im2col(const float* imgs, const int* ids_keep, void* cols, int out_dtype, int B, int C, int img,
+                               int p, int keep, void* stream) {
+  if (!imgs || !cols) return PM_EINVAL;
+  if (B <= 0 || C <= 0 || img <= 0 || p <= 0 || keep <= 0 || (img % p) || (p & 3)) return PM_ESHAPE;
+  const int L = (img / p) * (img / p);
+  if (keep > L || (!ids_keep && keep != L)) return PM_ESHAPE;
+  const dim3 grid(B * keep);
+  if (out_dtype == PM_BF16)
+    hipLaunchKernelGGL(im2col_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), imgs, ids_keep, (__bf16*)cols, C, img, p, keep);
+  else if (out_dtype == PM_F32)
+    hipLaunchKernelGGL(im2col_kernel<float>, grid, dim3(256), 0, pm_stream(stream), imgs, ids_keep, (float*)cols, C, img, p, keep);
+  else
+    return PM_EINVAL;
+  return pm_check_launch();
+}
+
+extern "C" int pm_assemble_tokens(const float* emb, const float* cls, const float* pos, const int* ids_keep, float* x,
+                                  int B, int keep, int D, void* stream) {
+  if (!emb || !cls || !pos || !x) return PM_EINVAL;
+  if (B <= 0 || keep <= 0 || D <= 0 || (D & 3)) return PM_ESHAPE;
+  hipLaunchKernelGGL(assemble_kernel, dim3(cap_grid((long)B * (keep + 1), 4, 4096)), dim3(256), 0, pm_stream(stream), emb,
+                     cls, pos, ids_keep, x, B, keep, D);
+  return pm_check_launch();
+}
+
+extern "C" int pm_assemble_tokens_bwd(const float* dx, const int* ids_keep, void* demb, int act_dtype, float* dcls,
+                                      float* dpos, int B, int keep, int D, void* stream) {
+  if (!dx || !demb) return PM_EINVAL;
+  if (B <= 0 || keep <= 0 || D <= 0 || (D & 3)) return PM_ESHAPE;
+  const dim3 grid(cap_grid((long)B * keep, 4, 4096));
+  if (act_dtype == PM_BF16)
+    hipLaunchKernelGGL(assemble_bwd_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), dx, ids_keep, (__bf16*)demb, dpos, B, keep, D);
+  else if (act_dtype == PM_F32)
+    hipLaunchKernelGGL(assemble_bwd_kernel<float>, grid, dim3(256), 0, pm_stream(stream), dx, ids_keep, (float*)demb, dpos, B, keep, D);
+  else
+    return PM_EINVAL;
+  if (dcls)
+    hipLaunchKernelGGL(cls_grad_kernel, dim3((D + 255) / 256), dim3(256), 0, pm_stream(stream), dx, dcls, dpos, B,
+                       (long)(keep + 1) * D, D);
+  return pm_check_launch();
+}
+
+extern "C" int pm_cast(const float* src, void* dst, int dst_dtype, long n, void* stream) {
+  if (!src || !dst) return PM_EINVAL;
+  if (n <= 0) return PM_ESHAPE;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return PM_EALIGN;
+  const dim3 grid(cap_grid(n >> 2, 256, 4096));
+  if (dst_dtype == PM_BF16)
+    hipLaunchKernelGGL(cast_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), src, (__bf16*)dst, n);
+  else if (dst_dtype == PM_F32)
+    hipLaunchKernelGGL(cast_kernel<float>, grid, dim3(256), 0, pm_stream(stream), src, (float*)dst, n);
+  else
+    return PM_EINVAL;
+  return pm_check_launch();
+}
+
+extern "C" int pm_cls_head_fwd(const float* x, int N, const float* gamma, const float* beta, const float* W,
+                               const float* bias, float* xn, float* mean, float* rstd, float* logits, int B, int D,
+                               int n_class, float eps, void* stream) {
+  if (!x || !gamma || !beta || !W || !xn || !mean || !rstd || !logits) return PM_EINVAL;
+  if (B <= 0 || N <= 0 || D <= 0 || D > 1024 || (D & 3) || n_class <= 0) return PM_ESHAPE;
+  hipLaunchKernelGGL(cls_head_fwd_kernel, dim3(B), dim3(64), 0, pm_stream(stream), x, (long)N * D, gamma, beta, W, bias, xn,
+                     mean, rstd, logits, D, n_class, eps);
+  return pm_check_launch();
+}
+
+extern "C" int pm_cls_head_bwd(const float* dlogits, const float* x, int N, const float* gamma, const float* W,
+                               const float* xn, const float* mean, const float* rstd, float* dx, void* dx_act,
+                               int act_dtype, float* dW, float* dbias, float* dgamma, float* dbeta, int B, int D,
+                               int n_class, void* stream) {
+  if (!dlogits || !x || !gamma || !W || !xn || !mean || !rstd) return PM_EINVAL;
+  if (!dx && dx_act) return PM_EINVAL;
+  if (B <= 0 || N <= 0 || D <= 0 || (D & 3) || n_class <= 0 || n_class > 256) return PM_ESHAPE;
+  if (act_dtype == PM_BF16)
+    hipLaunchKernelGGL(cls_head_bwd_kernel<__bf16>, dim3(B), dim3(256), 0, pm_stream(stream), dlogits, x, N, gamma, W, xn,
+                       mean, rstd, dx, (__bf16*)dx_act, dW, dbias, dgamma, dbeta, D, n_class);
+  else if (act_dtype == PM_F32)
+    hipLaunchKernelGGL(cls_head_bwd_kernel<float>, dim3(B), dim3(256), 0, pm_stream(stream), dlogits, x, N, gamma, W, xn,
+                       mean, rstd, dx, (float*)dx_act, dW, dbias, dgamma, dbeta, D, n_class);
+  else
+    return PM_EINVAL;
+  return pm_check_launch();
+}
+
+extern "C" int pm_adamw(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                        void* stream) {
+  if (!p || !g || !m || !v) return PM_EINVAL;
+  if (n <= 0 || (n & 3) || step < 1) return PM_ESHAPE;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const dim3 grid(cap_grid(n >> 2, 256, 4096));
+  if (!shadow || shadow_dtype == PM_BF16)
+    hipLaunchKernelGGL(adamw_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), p, g, m, v, (__bf16*)shadow, n, lr, beta1,
+                       beta2, eps, weight_decay, (float)bc1, rsqrt_bc2, grad_scale);
+  else if (shadow_dtype == PM_F32)
+    hipLaunchKernelGGL(adamw_kernel<float>, grid, dim3(256), 0, pm_stream(stream), p, g, m, v, (float*)shadow, n, lr, beta1,
+                       beta2, eps, weight_decay, (float)bc1, rsqrt_bc2, grad_scale);
+  else
+    return PM_EINVAL;
+  return pm_check_launch();
+}
+
+
+extern "C" int pm_grad_stats(const float* g, long n, float* out, void* stream) {
+  if (!g || !out) return PM_EINVAL;
+  if (n <= 0) return PM_ESHAPE;
+  if ((uintptr_t)g & 15) return PM_EALIGN;
+  hipLaunchKernelGGL(grad_stats_kernel, dim3(cap_grid(n >> 2, 256, 1024)), dim3(256), 0, pm_stream(stream), g, n, out);
+  return pm_check_launch();
+}
+
+extern "C" const char* pm_strerror(int status) {
+  switch (status) {
+    case PM_OK: return "ok";
+    case PM_EINVAL: return "invalid argument (null pointer / unknown dtype or epilogue)";
+    case PM_ESHAPE: return "unsupported shape";
+    case PM_EARCH: return "no gfx950 device";
+    case PM_ELAUNCH: return "kernel launch failed";
+    case PM_EALIGN: return "pointer / leading dimension not 16-byte aligned";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int pm_abi_version(void) { return 1; }

@@ -1,0 +1,235 @@
+"""Host-side execution engine: sequences the HIP kernels of one ViT / MAE training step.
+
+This is the MI355X-native counterpart of the torch/timm op graph that the reference builds in
+``MaskedAutoencoderViT.forward`` (src/ssl4polyp/models/mae/models_mae.py:150-220) and
+``ViT_from_MAE.forward`` / ``VisionTransformer_from_Any.forward`` (src/ssl4polyp/models/models.py:117-140,
+196-222) plus autograd's backward of it.  Instead of ~14 library launches per block with the [N,N]
+attention scores, GELU and residual tensors round-tripping HBM, a block is 7 launches forward
+(LN, qkv GEMM, fused attention, proj GEMM+residual, LN, fc1 GEMM+GELU, fc2 GEMM+residual) and the whole
+forward/backward is ONE autograd node, so the engine owns every intermediate buffer, their dtypes
+(bf16 activations, f32 residual stream and statistics) and the order in which gradients become ready
+(which drives the RCCL bucket all-reduce, see parallel.py).
+
+PyTorch is used for device memory (caching allocator), streams and autograd plumbing only; all
+arithmetic is in libpolypmae.so.  No CPU / eager fallback exists.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import EPI_ACCUM, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, EPI_STORE, PM_BF16, PM_F32
+
+LN_EPS = 1e-6  # models_mae.py:227, models.py:164: partial(nn.LayerNorm, eps=1e-6)
+
+BLOCK_PARAM_NAMES = (
+    "norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+    "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Kernels:
+    """Thin typed wrappers: torch tensors in, C-ABI calls out (include/polypmae.h)."""
+
+    def __init__(self, precision: str, eps: float = LN_EPS):
+        self.eps = float(eps)
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.lib = _lib.load()
+        self.precision = precision
+        self.act_dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.act = PM_BF16 if precision == "bf16" else PM_F32
+
+    # -- helpers ------------------------------------------------------------------------------
+    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, M, D):
+        _lib.check(self.lib.pm_layernorm_fwd(_ptr(x), D, _ptr(gamma), _ptr(beta), _ptr(y), _lib.dtype_code(y.dtype),
+                                             _ptr(mean), _ptr(rstd), M, D, self.eps, _stream()), "pm_layernorm_fwd")
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dres, dx, dx_act, dgamma, dbeta, dcolsum, M, D):
+        _lib.check(self.lib.pm_layernorm_bwd(_ptr(dy), _lib.dtype_code(dy.dtype), _ptr(x), D, _ptr(gamma), _ptr(mean),
+                                             _ptr(rstd), _ptr(dres), D, _ptr(dx), D, _ptr(dx_act), self.act,
+                                             _ptr(dgamma), _ptr(dbeta), _ptr(dcolsum), M, D, _stream()),
+                   "pm_layernorm_bwd")
+
+    def gemm(self, A, lda, a_kmajor, B, ldb, b_kmajor, bias, C, ldc, epilogue, M, N, K, aux=None, resid=None):
+        in_dtype = _lib.dtype_code(A.dtype)
+        if _lib.dtype_code(B.dtype) != in_dtype:
+            raise _lib.PolypMaeError("pm_gemm: operand dtypes differ")
+        _lib.check(self.lib.pm_gemm(_ptr(A), lda, int(a_kmajor), _ptr(B), ldb, int(b_kmajor), in_dtype, _ptr(bias),
+                                    _ptr(C), ldc, _lib.dtype_code(C.dtype), epilogue, _ptr(aux), _ptr(resid), M, N, K,
+                                    _stream()), "pm_gemm")
+
+    def linear_fwd(self, x, W, bias, out, M, N, K, epilogue=EPI_STORE, aux=None, resid=None):
+        """out[M,N] = x[M,K] @ W[N,K]^T + bias  (nn.Linear forward)."""
+        self.gemm(x, K, 0, W, K, 0, bias, out, N, epilogue, M, N, K, aux=aux, resid=resid)
+
+    def linear_dgrad(self, dy, W, dx, M, N_out, K_in, epilogue=EPI_STORE, aux=None):
+        """dx[M,K_in] = dy[M,N_out] @ W[N_out,K_in]  (W read as stored: k-major B operand)."""
+        self.gemm(dy, N_out, 0, W, K_in, 1, None, dx, K_in, epilogue, M, K_in, N_out, aux=aux)
+
+    def linear_wgrad(self, dy, x, dW, M, N_out, K_in, accumulate):
+        """dW[N_out,K_in] (+)= dy[M,N_out]^T @ x[M,K_in]  (both operands k-major, f32 output)."""
+        self.gemm(dy, N_out, 1, x, K_in, 1, None, dW, K_in, EPI_ACCUM if accumulate else EPI_STORE, N_out, K_in, M)
+
+    def colsum(self, x, out, M, N):
+        _lib.check(self.lib.pm_colsum(_ptr(x), N, _lib.dtype_code(x.dtype), _ptr(out), M, N, _stream()), "pm_colsum")
+
+    def attention_fwd(self, qkv, out, lse, B, N, H, dh):
+        _lib.check(self.lib.pm_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, N, H, dh, self.act, _stream()),
+                   "pm_attention_fwd")
+
+    def attention_bwd(self, qkv, out, dout, lse, delta, dqkv, B, N, H, dh):
+        _lib.check(self.lib.pm_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(delta), _ptr(dqkv), B, N,
+                                             H, dh, self.act, _stream()), "pm_attention_bwd")
+
+    def cast(self, src, dst):
+        _lib.check(self.lib.pm_cast(_ptr(src), _ptr(dst), _lib.dtype_code(dst.dtype), src.numel(), _stream()), "pm_cast")
+
+
+@dataclass
+class StackGeom:
+    """Geometry of one stack of pre-LN transformer blocks (timm Block)."""
+    dim: int
+    heads: int
+    depth: int
+    hidden: int
+
+    @property
+    def dh(self) -> int:
+        return self.dim // self.heads
+
+
+class BlockWorkspace:
+    """Saved-for-backward activations of one block at (B, N).  Everything the backward needs, nothing else."""
+
+    def __init__(self, g: StackGeom, B: int, N: int, act_dtype, dev):
+        M, D, Hd = B * N, g.dim, g.hidden
+        f32 = torch.float32
+        e = lambda *s, dt=act_dtype: torch.empty(*s, dtype=dt, device=dev)
+        self.mean1, self.rstd1 = e(M, dt=f32), e(M, dt=f32)
+        self.ln1 = e(M, D)
+        self.qkv = e(M, 3 * D)
+        self.lse = e(B * g.heads * N, dt=f32)
+        self.attn = e(M, D)
+        self.x_mid = e(M, D, dt=f32)
+        self.mean2, self.rstd2 = e(M, dt=f32), e(M, dt=f32)
+        self.ln2 = e(M, D)
+        self.h_pre = e(M, Hd)
+        self.h_act = e(M, Hd)
+        self.x_out = e(M, D, dt=f32)
+
+
+class StackWorkspace:
+    """Per-(B,N) buffers of a whole block stack: per-block saves + shared backward temporaries."""
+
+    def __init__(self, g: StackGeom, B: int, N: int, act_dtype, dev, training: bool):
+        self.B, self.N, self.M = B, N, B * N
+        M, D, Hd = self.M, g.dim, g.hidden
+        f32 = torch.float32
+        nblk = g.depth if training else min(g.depth, 2)
+        self.blocks = [BlockWorkspace(g, B, N, act_dtype, dev) for _ in range(nblk)]
+        self.training = training
+        if training:
+            e = lambda *s, dt=act_dtype: torch.empty(*s, dtype=dt, device=dev)
+            self.d_hidden = e(M, Hd)
+            self.d_ln = e(M, D)
+            self.d_attn = e(M, D)
+            self.d_qkv = e(M, 3 * D)
+            self.delta = e(B * g.heads * N, dt=f32)
+            self.dx = [e(M, D, dt=f32), e(M, D, dt=f32)]
+            self.dx_act = [e(M, D), e(M, D)]
+
+    def block(self, i: int) -> BlockWorkspace:
+        return self.blocks[i if self.training else i % len(self.blocks)]
+
+
+class BlockStack:
+    """Runs `depth` transformer blocks forward / backward over an f32 residual stream."""
+
+    def __init__(self, k: Kernels, g: StackGeom):
+        self.k, self.g = k, g
+
+    def forward(self, ws: StackWorkspace, x_in: torch.Tensor, W: Sequence[Dict[str, torch.Tensor]]) -> torch.Tensor:
+        """x_in f32 [M, D]; W[i] maps BLOCK_PARAM_NAMES -> tensors (matrices act-typed, vectors f32)."""
+        k, g = self.k, self.g
+        B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
+        x = x_in
+        for i in range(g.depth):
+            bw, p = ws.block(i), W[i]
+            k.layernorm_fwd(x, p["norm1.weight"], p["norm1.bias"], bw.ln1, bw.mean1, bw.rstd1, M, D)
+            k.linear_fwd(bw.ln1, p["attn.qkv.weight"], p["attn.qkv.bias"], bw.qkv, M, 3 * D, D)
+            k.attention_fwd(bw.qkv, bw.attn, bw.lse, B, N, g.heads, g.dh)
+            k.linear_fwd(bw.attn, p["attn.proj.weight"], p["attn.proj.bias"], bw.x_mid, M, D, D, EPI_RESIDUAL, resid=x)
+            k.layernorm_fwd(bw.x_mid, p["norm2.weight"], p["norm2.bias"], bw.ln2, bw.mean2, bw.rstd2, M, D)
+            k.linear_fwd(bw.ln2, p["mlp.fc1.weight"], p["mlp.fc1.bias"], bw.h_act, M, Hd, D, EPI_GELU, aux=bw.h_pre)
+            k.linear_fwd(bw.h_act, p["mlp.fc2.weight"], p["mlp.fc2.bias"], bw.x_out, M, D, Hd, EPI_RESIDUAL,
+                         resid=bw.x_mid)
+            x = bw.x_out
+        return x
+
+    def backward(self, ws: StackWorkspace, x_in: torch.Tensor, W, G, dx: torch.Tensor, dx_act: torch.Tensor,
+                 last_bias_grad_done: bool, trainable: Sequence[bool], need_input_grad: bool,
+                 accumulate: Callable[[str, int], bool], on_block_done: Optional[Callable[[int], None]] = None,
+                 prev_bias_grad: Optional[torch.Tensor] = None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        """dx / dx_act: gradient w.r.t. the stack output (f32 + act copy).  G[i][name] = f32 gradient
+        tensors (vectors are += targets and must be zeroed or hold the running sum; matrices follow
+        accumulate(name, i)).  `last_bias_grad_done`: the producer of dx already added colsum(dx) into the
+        last block's fc2.bias gradient.  `prev_bias_grad`: bias gradient of the Linear that produced the
+        stack input (receives colsum of the input gradient), if any.
+        Returns (dx_in f32, dx_in act) or (None, None) when nothing below needs it."""
+        k, g = self.k, self.g
+        B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
+        lowest = min([i for i, t in enumerate(trainable) if t], default=g.depth)
+        for i in reversed(range(g.depth)):
+            if i < lowest and not need_input_grad:
+                return None, None
+            bw, p, gr, tr = ws.block(i), W[i], G[i], trainable[i]
+            xin = x_in if i == 0 else ws.block(i - 1).x_out
+            need_dx_in = need_input_grad or i > lowest
+            o = i & 1
+            dmid, dmid_act = ws.dx[o], ws.dx_act[o]
+            din, din_act = ws.dx[o ^ 1], ws.dx_act[o ^ 1]
+            if i == g.depth - 1 and not last_bias_grad_done and tr:
+                k.colsum(dx, gr["mlp.fc2.bias"], M, D)
+            # ---- MLP branch ----
+            k.linear_dgrad(dx_act, p["mlp.fc2.weight"], ws.d_hidden, M, D, Hd, EPI_DGELU, aux=bw.h_pre)
+            if tr:
+                k.linear_wgrad(dx_act, bw.h_act, gr["mlp.fc2.weight"], M, D, Hd, accumulate("mlp.fc2.weight", i))
+                k.linear_wgrad(ws.d_hidden, bw.ln2, gr["mlp.fc1.weight"], M, Hd, D, accumulate("mlp.fc1.weight", i))
+                k.colsum(ws.d_hidden, gr["mlp.fc1.bias"], M, Hd)
+            k.linear_dgrad(ws.d_hidden, p["mlp.fc1.weight"], ws.d_ln, M, Hd, D)
+            k.layernorm_bwd(ws.d_ln, bw.x_mid, p["norm2.weight"], bw.mean2, bw.rstd2, dx, dmid, dmid_act,
+                            gr["norm2.weight"] if tr else None, gr["norm2.bias"] if tr else None,
+                            gr["attn.proj.bias"] if tr else None, M, D)
+            # ---- attention branch ----
+            k.linear_dgrad(dmid_act, p["attn.proj.weight"], ws.d_attn, M, D, D)
+            if tr:
+                k.linear_wgrad(dmid_act, bw.attn, gr["attn.proj.weight"], M, D, D, accumulate("attn.proj.weight", i))
+            k.attention_bwd(bw.qkv, bw.attn, ws.d_attn, bw.lse, ws.delta, ws.d_qkv, B, N, g.heads, g.dh)
+            if tr:
+                k.linear_wgrad(ws.d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, accumulate("attn.qkv.weight", i))
+                k.colsum(ws.d_qkv, gr["attn.qkv.bias"], M, 3 * D)
+            if not need_dx_in and not tr:
+                return None, None
+            k.linear_dgrad(ws.d_qkv, p["attn.qkv.weight"], ws.d_ln, M, 3 * D, D)
+            below_bias = None
+            if i > 0 and trainable[i - 1]:
+                below_bias = G[i - 1]["mlp.fc2.bias"]
+            elif i == 0:
+                below_bias = prev_bias_grad
+            k.layernorm_bwd(ws.d_ln, xin, p["norm1.weight"], bw.mean1, bw.rstd1, dmid, din, din_act,
+                            gr["norm1.weight"] if tr else None, gr["norm1.bias"] if tr else None, below_bias, M, D)
+            dx, dx_act = din, din_act
+            if on_block_done is not None:
+                on_block_done(i)
+        return dx, dx_act

@@ -1,0 +1,687 @@
+"""Drop-in model classes for the SSL4POLYP hot path, executed by the MI355X engine.
+
+Mirrors (same class names, constructor arguments, attribute surface and state-dict keys):
+  src/ssl4polyp/models/mae/models_mae.py:22-250   MaskedAutoencoderViT, mae_vit_{base,large,huge}_*
+  src/ssl4polyp/models/models.py:26-140           VisionTransformer_from_Any
+  src/ssl4polyp/models/models.py:143-222          ViT_from_MAE
+The sub-modules (nn.Conv2d / nn.Linear / nn.LayerNorm) are PARAMETER CONTAINERS with the reference's
+names and initialisation order -- their own forward is never called; the arithmetic runs as one autograd
+node over the HIP kernels (engine.py).  There is no eager fallback: on a CPU tensor forward raises.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import (BLOCK_PARAM_NAMES, EPI_STORE, BlockStack, Kernels, StackGeom, StackWorkspace, _ptr, _stream)
+from .flat import FlatParams
+
+_DEFAULT_PRECISION = "bf16"
+
+
+# --------------------------------------------------------------------------------------------------
+# positional tables (pos_embed.py:20-67): numpy float64, first D/2 channels from grid w, second from h
+# --------------------------------------------------------------------------------------------------
+def get_1d_sincos_pos_embed_from_grid(embed_dim, pos):
+    assert embed_dim % 2 == 0
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False):
+    grid_h = np.arange(grid_size, dtype=np.float32)
+    grid_w = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0).reshape([2, 1, grid_size, grid_size])
+    assert embed_dim % 2 == 0
+    emb = np.concatenate([get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[0]),
+                          get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[1])], axis=1)
+    if cls_token:
+        emb = np.concatenate([np.zeros([1, embed_dim]), emb], axis=0)
+    return emb
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter containers with timm 0.4.12's module / parameter names and construction order
+# --------------------------------------------------------------------------------------------------
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias=True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads, qkv_bias=qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+# --------------------------------------------------------------------------------------------------
+# runtime: binds a module's parameters to the engine
+# --------------------------------------------------------------------------------------------------
+class _Runtime:
+    """Per-model engine state: kernels, flat storage, block stacks, workspace pool, grad-sync hook."""
+
+    def __init__(self, module: nn.Module, precision: str, enc: StackGeom, dec: Optional[StackGeom]):
+        self.module = module
+        self.precision = precision
+        self.enc_geom, self.dec_geom = enc, dec
+        self.k: Optional[Kernels] = None
+        self.flat: Optional[FlatParams] = None
+        self.pool: Dict[tuple, List[StackWorkspace]] = {}
+        self.grad_sync = None  # parallel.GradSync, set by DataParallel wrapper
+        self._wcache: Dict[str, tuple] = {}
+        self.eps = 1e-6
+
+    def ensure(self, device: torch.device) -> None:
+        if device.type != "cuda":
+            raise _lib.PolypMaeError("ssl4polyp_amd models run on the MI355X HIP path only (got a CPU tensor); "
+                                     "there is no eager fallback")
+        if self.k is None:
+            self.k = Kernels(self.precision, self.eps)
+        if self.flat is None or set(self.flat.names) != {n for n, _ in self.module.named_parameters()}:
+            self.flat = FlatParams(self.module, self.k.act_dtype)
+        if not self.flat.bound(device):
+            self.flat.materialize(device)
+            self.pool.clear()
+            self._wcache = {}
+        if self.flat.shadow_stale():
+            self.k.cast(self.flat.P["mat"], self.flat.S)
+            self.flat.mark_shadow_fresh()
+
+    # weights / grads of one block stack as dicts of persistent views
+    def stack_weights(self, prefix: str, depth: int):
+        hit = self._wcache.get(prefix)
+        if hit is not None:
+            return hit
+        f = self.flat
+        W, G = [], []
+        for i in range(depth):
+            w, g = {}, {}
+            for n in BLOCK_PARAM_NAMES:
+                full = f"{prefix}{i}.{n}"
+                w[n] = f.shadow_view(full) if n.endswith("weight") and "norm" not in n else f.param_view(full)
+                g[n] = f.grad_view(full)
+            W.append(w)
+            G.append(g)
+        self._wcache[prefix] = (W, G)
+        return W, G
+
+    def get_ws(self, geom: StackGeom, B: int, N: int, training: bool) -> StackWorkspace:
+        key = (geom.dim, geom.depth, B, N, training)
+        lst = self.pool.setdefault(key, [])
+        if lst:
+            return lst.pop()
+        return StackWorkspace(geom, B, N, self.k.act_dtype, self.flat.device, training)
+
+    def put_ws(self, geom: StackGeom, ws: StackWorkspace) -> None:
+        self.pool.setdefault((geom.dim, geom.depth, ws.B, ws.N, ws.training), []).append(ws)
+
+
+def _plan_grads(rt: _Runtime, names: List[str], needs: List[bool]):
+    """Decide fresh vs accumulate-in-place for this backward (see flat.py) and prepare the flat ranges."""
+    f = rt.flat
+    tr = [n for n, need in zip(names, needs) if need]
+    flat_state = [f.grad_is_flat(n) for n in tr]
+    if tr and all(flat_state):
+        return True
+    if any(flat_state):
+        raise _lib.PolypMaeError("some parameter .grad tensors alias the engine's flat gradient buffer and others do "
+                                 "not; call optimizer.zero_grad() for all parameters consistently")
+    f.G["vec"].zero_()
+    return False
+
+
+class _EncoderFrontMixin:
+    """Patch-embed + token assembly shared by both paths."""
+
+    @staticmethod
+    def front_fwd(rt: _Runtime, imgs, ids_keep, keep, pos_name="pos_embed"):
+        k, f, mod = rt.k, rt.flat, rt.module
+        B, C, img = imgs.shape[0], imgs.shape[1], imgs.shape[2]
+        p = mod.patch_embed.patch_size[0]
+        D = rt.enc_geom.dim
+        PE = C * p * p
+        dev = imgs.device
+        cols = torch.empty(B * keep, PE, dtype=k.act_dtype, device=dev)
+        _lib.check(k.lib.pm_patch_im2col(_ptr(imgs), _ptr(ids_keep), _ptr(cols), k.act, B, C, img, p, keep, _stream()),
+                   "pm_patch_im2col")
+        emb = torch.empty(B * keep, D, dtype=torch.float32, device=dev)
+        k.linear_fwd(cols, f.shadow_view("patch_embed.proj.weight").view(D, PE), f.param_view("patch_embed.proj.bias"),
+                     emb, B * keep, D, PE)
+        x0 = torch.empty(B * (keep + 1), D, dtype=torch.float32, device=dev)
+        _lib.check(k.lib.pm_assemble_tokens(_ptr(emb), _ptr(f.param_view("cls_token")), _ptr(f.param_view(pos_name)),
+                                            _ptr(ids_keep), _ptr(x0), B, keep, D, _stream()), "pm_assemble_tokens")
+        return cols, x0
+
+    @staticmethod
+    def front_bwd(rt: _Runtime, dx0, cols, ids_keep, B, keep, accumulate, need, learn_pos):
+        k, f = rt.k, rt.flat
+        D = rt.enc_geom.dim
+        PE = cols.shape[1]
+        demb = torch.empty(B * keep, D, dtype=k.act_dtype, device=cols.device)
+        dcls = f.grad_view("cls_token") if need("cls_token") else None
+        dpos = f.grad_view("pos_embed") if learn_pos and need("pos_embed") else None
+        _lib.check(k.lib.pm_assemble_tokens_bwd(_ptr(dx0), _ptr(ids_keep), _ptr(demb), k.act, _ptr(dcls), _ptr(dpos), B,
+                                                keep, D, _stream()), "pm_assemble_tokens_bwd")
+        if need("patch_embed.proj.weight"):
+            k.linear_wgrad(demb, cols, f.grad_view("patch_embed.proj.weight").view(D, PE), B * keep, D, PE, accumulate)
+        if need("patch_embed.proj.bias"):
+            k.colsum(demb, f.grad_view("patch_embed.proj.bias"), B * keep, D)
+
+
+class _VitClsFn(torch.autograd.Function):
+    """imgs -> logits for ViT_from_MAE / VisionTransformer_from_Any (models.py:129-140, 211-222), one node."""
+
+    @staticmethod
+    def forward(ctx, rt: _Runtime, imgs: torch.Tensor, names, *params):
+        k, f, mod, g = rt.k, rt.flat, rt.module, rt.enc_geom
+        B = imgs.shape[0]
+        L = mod.patch_embed.num_patches
+        N = L + 1
+        D = g.dim
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        imgs = imgs.contiguous().float()
+        cols, x0 = _EncoderFrontMixin.front_fwd(rt, imgs, None, L)
+        ws = rt.get_ws(g, B, N, training)
+        W, _ = rt.stack_weights("blocks.", g.depth)
+        x = BlockStack(k, g).forward(ws, x0, W)
+        n_class = mod.lin_head.weight.shape[0]
+        dev = imgs.device
+        xn = torch.empty(B, D, dtype=torch.float32, device=dev)
+        mean = torch.empty(B, dtype=torch.float32, device=dev)
+        rstd = torch.empty(B, dtype=torch.float32, device=dev)
+        logits = torch.empty(B, n_class, dtype=torch.float32, device=dev)
+        _lib.check(k.lib.pm_cls_head_fwd(_ptr(x), N, _ptr(f.param_view("norm.weight")), _ptr(f.param_view("norm.bias")),
+                                         _ptr(f.param_view("lin_head.weight")), _ptr(f.param_view("lin_head.bias")),
+                                         _ptr(xn), _ptr(mean), _ptr(rstd), _ptr(logits), B, D, n_class, rt.eps, _stream()),
+                   "pm_cls_head_fwd")
+        if training:
+            ctx.rt, ctx.names, ctx.ws = rt, names, ws
+            ctx.saved = (cols, x0, x, xn, mean, rstd)
+            ctx.dims = (B, L, N, D, n_class)
+        else:
+            rt.put_ws(g, ws)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        rt, names, ws = ctx.rt, ctx.names, ctx.ws
+        k, f, mod, g = rt.k, rt.flat, rt.module, rt.enc_geom
+        cols, x0, x, xn, mean, rstd = ctx.saved
+        B, L, N, D, n_class = ctx.dims
+        needs = list(ctx.needs_input_grad[3:])
+        need_map = dict(zip(names, needs))
+        need = lambda n: need_map.get(n, False)
+        accumulate = _plan_grads(rt, names, needs)
+        if not accumulate and need("lin_head.weight"):
+            f.grad_view("lin_head.weight").zero_()
+        trainable = [any(need(f"blocks.{i}.{n}") for n in BLOCK_PARAM_NAMES) for i in range(g.depth)]
+        learn_pos = bool(getattr(mod, "_learned_pos", False))
+        front = need("cls_token") or need("patch_embed.proj.weight") or need("patch_embed.proj.bias") or \
+            (learn_pos and need("pos_embed"))
+        below_head = front or any(trainable)
+        dlogits = dlogits.contiguous().float()
+        dx = ws.dx[0] if below_head else None
+        dx_act = ws.dx_act[0] if below_head else None
+        _lib.check(k.lib.pm_cls_head_bwd(
+            _ptr(dlogits), _ptr(x), N, _ptr(f.param_view("norm.weight")), _ptr(f.param_view("lin_head.weight")), _ptr(xn),
+            _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dx_act), k.act,
+            _ptr(f.grad_view("lin_head.weight")) if need("lin_head.weight") else None,
+            _ptr(f.grad_view("lin_head.bias")) if need("lin_head.bias") else None,
+            _ptr(f.grad_view("norm.weight")) if need("norm.weight") else None,
+            _ptr(f.grad_view("norm.bias")) if need("norm.bias") else None, B, D, n_class, _stream()), "pm_cls_head_bwd")
+        sync = rt.grad_sync
+        if below_head:
+            W, G = rt.stack_weights("blocks.", g.depth)
+            cb = (lambda i: sync.block_done("blocks.", i)) if sync is not None else None
+            # the incoming dx lives in ws.dx[0]; an odd-depth stack would start writing ws.dx[1] first: fine either way
+            dx0, _ = BlockStack(k, g).backward(ws, x0, W, G, dx, dx_act, False, trainable, front,
+                                               lambda n, i: accumulate, cb)
+            if front and dx0 is not None:
+                _EncoderFrontMixin.front_bwd(rt, dx0, cols, None, B, L, accumulate, need, learn_pos)
+        if sync is not None:
+            sync.backward_done()
+        rt.put_ws(g, ws)
+        ctx.saved = None
+        grads = [None if (accumulate or not nd) else f.grad_view(n) for n, nd in zip(names, needs)]
+        return (None, None, None, *grads)
+
+
+class _MaeFn(torch.autograd.Function):
+    """imgs (+noise) -> (loss, pred, mask) for MaskedAutoencoderViT.forward (models_mae.py:216-220), one node."""
+
+    @staticmethod
+    def forward(ctx, rt: _Runtime, imgs, noise, mask_ratio, names, *params):
+        k, f, mod, ge, gd = rt.k, rt.flat, rt.module, rt.enc_geom, rt.dec_geom
+        B, C, img = imgs.shape[0], imgs.shape[1], imgs.shape[2]
+        p = mod.patch_embed.patch_size[0]
+        L = mod.patch_embed.num_patches
+        keep = int(L * (1 - mask_ratio))  # models_mae.py:130
+        if keep < 1:
+            raise ValueError("mask_ratio leaves no visible patch")
+        De, Dd, PE = ge.dim, gd.dim, p * p * C
+        dev = imgs.device
+        f32 = torch.float32
+        training = torch.is_grad_enabled() and any(q.requires_grad for q in params)
+        imgs = imgs.contiguous().float()
+        ctx.set_materialize_grads(False)
+        # -- masking (models_mae.py:123-148)
+        ids_shuffle = torch.empty(B, L, dtype=torch.int32, device=dev)
+        ids_restore = torch.empty(B, L, dtype=torch.int32, device=dev)
+        mask = torch.empty(B, L, dtype=f32, device=dev)
+        noise = noise.contiguous().float()
+        _lib.check(k.lib.pm_mae_masking(_ptr(noise), _ptr(ids_shuffle), _ptr(ids_restore), _ptr(mask), B, L, keep,
+                                        _stream()), "pm_mae_masking")
+        ids_keep = ids_shuffle[:, :keep].contiguous()
+        # -- encoder on the kept patches only (the projection is per patch, so gather-then-embed == embed-then-gather)
+        cols, x0 = _EncoderFrontMixin.front_fwd(rt, imgs, ids_keep, keep)
+        ws_e = rt.get_ws(ge, B, keep + 1, training)
+        We, _ = rt.stack_weights("blocks.", ge.depth)
+        xe = BlockStack(k, ge).forward(ws_e, x0, We)
+        Me, Md = B * (keep + 1), B * (L + 1)
+        latent = torch.empty(Me, De, dtype=k.act_dtype, device=dev)
+        mean_e, rstd_e = torch.empty(Me, dtype=f32, device=dev), torch.empty(Me, dtype=f32, device=dev)
+        k.layernorm_fwd(xe, f.param_view("norm.weight"), f.param_view("norm.bias"), latent, mean_e, rstd_e, Me, De)
+        # -- decoder (models_mae.py:172-196)
+        demb = torch.empty(Me, Dd, dtype=f32, device=dev)
+        k.linear_fwd(latent, f.shadow_view("decoder_embed.weight"), f.param_view("decoder_embed.bias"), demb, Me, Dd, De)
+        xd0 = torch.empty(Md, Dd, dtype=f32, device=dev)
+        _lib.check(k.lib.pm_mae_unshuffle(_ptr(demb), _ptr(f.param_view("mask_token")),
+                                          _ptr(f.param_view("decoder_pos_embed")), _ptr(ids_restore), _ptr(xd0), B, L,
+                                          keep, Dd, _stream()), "pm_mae_unshuffle")
+        ws_d = rt.get_ws(gd, B, L + 1, training)
+        Wd, _ = rt.stack_weights("decoder_blocks.", gd.depth)
+        xd = BlockStack(k, gd).forward(ws_d, xd0, Wd)
+        yn = torch.empty(Md, Dd, dtype=k.act_dtype, device=dev)
+        mean_d, rstd_d = torch.empty(Md, dtype=f32, device=dev), torch.empty(Md, dtype=f32, device=dev)
+        k.layernorm_fwd(xd, f.param_view("decoder_norm.weight"), f.param_view("decoder_norm.bias"), yn, mean_d, rstd_d,
+                        Md, Dd)
+        pred_full = torch.empty(B, L + 1, PE, dtype=f32, device=dev)
+        k.linear_fwd(yn, f.shadow_view("decoder_pred.weight"), f.param_view("decoder_pred.bias"), pred_full, Md, PE, Dd)
+        # -- loss (models_mae.py:198-214)
+        patch_loss = torch.empty(B * L, dtype=f32, device=dev)
+        sums = torch.empty(2, dtype=f32, device=dev)
+        loss = torch.empty(1, dtype=f32, device=dev)
+        npx = 1 if mod.norm_pix_loss else 0
+        _lib.check(k.lib.pm_mae_loss_fwd(_ptr(imgs), _ptr(pred_full), PE, 1, _ptr(patch_loss), B, C, img, p, npx,
+                                         _stream()), "pm_mae_loss_fwd")
+        _lib.check(k.lib.pm_mae_loss_finish(_ptr(patch_loss), _ptr(mask), B * L, _ptr(sums), _ptr(loss), _stream()),
+                   "pm_mae_loss_finish")
+        pred = pred_full[:, 1:, :]
+        if training:
+            ctx.rt, ctx.names = rt, names
+            ctx.ws = (ws_e, ws_d)
+            ctx.saved = (imgs, ids_keep, ids_shuffle, mask, cols, x0, xe, latent, mean_e, rstd_e, xd0, xd, yn, mean_d,
+                         rstd_d, pred_full, sums)
+            ctx.dims = (B, C, img, p, L, keep, npx)
+            ctx.mark_non_differentiable(mask)
+        else:
+            rt.put_ws(ge, ws_e)
+            rt.put_ws(gd, ws_d)
+        return loss.reshape(()), pred, mask
+
+    @staticmethod
+    def backward(ctx, dloss, dpred, dmask):
+        if dpred is not None:
+            raise NotImplementedError("gradients flowing into `pred` from outside the MAE loss are not supported")
+        rt, names = ctx.rt, ctx.names
+        k, f, mod, ge, gd = rt.k, rt.flat, rt.module, rt.enc_geom, rt.dec_geom
+        ws_e, ws_d = ctx.ws
+        (imgs, ids_keep, ids_shuffle, mask, cols, x0, xe, latent, mean_e, rstd_e, xd0, xd, yn, mean_d, rstd_d, pred_full,
+         sums) = ctx.saved
+        B, C, img, p, L, keep, npx = ctx.dims
+        De, Dd, PE = ge.dim, gd.dim, p * p * C
+        Me, Md = B * (keep + 1), B * (L + 1)
+        dev = imgs.device
+        needs = list(ctx.needs_input_grad[5:])
+        need_map = dict(zip(names, needs))
+        need = lambda n: need_map.get(n, False)
+        accumulate = _plan_grads(rt, names, needs)
+        acc_fn = lambda n, i: accumulate
+        sync = rt.grad_sync
+        if dloss is None:
+            dloss = torch.zeros((), dtype=torch.float32, device=dev)
+        dloss = dloss.reshape(1).contiguous().float()
+        # -- loss + decoder_pred
+        dpred_act = torch.empty(Md, PE, dtype=k.act_dtype, device=dev)
+        _lib.check(k.lib.pm_mae_loss_bwd(_ptr(imgs), _ptr(pred_full), PE, 1, _ptr(mask), _ptr(sums), _ptr(dloss),
+                                         _ptr(dpred_act), k.act, B, C, img, p, npx, _stream()), "pm_mae_loss_bwd")
+        if need("decoder_pred.weight"):
+            k.linear_wgrad(dpred_act, yn, f.grad_view("decoder_pred.weight"), Md, PE, Dd, accumulate)
+        if need("decoder_pred.bias"):
+            k.colsum(dpred_act, f.grad_view("decoder_pred.bias"), Md, PE)
+        k.linear_dgrad(dpred_act, f.shadow_view("decoder_pred.weight"), ws_d.d_ln, Md, PE, Dd)
+        Wd, Gd = rt.stack_weights("decoder_blocks.", gd.depth)
+        tr_d = [any(need(f"decoder_blocks.{i}.{n}") for n in BLOCK_PARAM_NAMES) for i in range(gd.depth)]
+        last = gd.depth - 1
+        k.layernorm_bwd(ws_d.d_ln, xd, f.param_view("decoder_norm.weight"), mean_d, rstd_d, None, ws_d.dx[last & 1 ^ 1],
+                        ws_d.dx_act[last & 1 ^ 1],
+                        f.grad_view("decoder_norm.weight") if need("decoder_norm.weight") else None,
+                        f.grad_view("decoder_norm.bias") if need("decoder_norm.bias") else None,
+                        Gd[last]["mlp.fc2.bias"] if tr_d[last] else None, Md, Dd)
+        cb_d = (lambda i: sync.block_done("decoder_blocks.", i)) if sync is not None else None
+        dxd0, _ = BlockStack(k, gd).backward(ws_d, xd0, Wd, Gd, ws_d.dx[last & 1 ^ 1], ws_d.dx_act[last & 1 ^ 1], True, tr_d,
+                                             True, acc_fn, cb_d)
+        # -- un-shuffle + decoder_embed
+        demb_act = torch.empty(Me, Dd, dtype=k.act_dtype, device=dev)
+        _lib.check(k.lib.pm_mae_unshuffle_bwd(_ptr(dxd0), _ptr(ids_shuffle), _ptr(demb_act), k.act,
+                                              _ptr(f.grad_view("mask_token")) if need("mask_token") else None, B, L, keep,
+                                              Dd, _stream()), "pm_mae_unshuffle_bwd")
+        if need("decoder_embed.weight"):
+            k.linear_wgrad(demb_act, latent, f.grad_view("decoder_embed.weight"), Me, Dd, De, accumulate)
+        if need("decoder_embed.bias"):
+            k.colsum(demb_act, f.grad_view("decoder_embed.bias"), Me, Dd)
+        k.linear_dgrad(demb_act, f.shadow_view("decoder_embed.weight"), ws_e.d_ln, Me, Dd, De)
+        # -- encoder
+        We, Ge = rt.stack_weights("blocks.", ge.depth)
+        tr_e = [any(need(f"blocks.{i}.{n}") for n in BLOCK_PARAM_NAMES) for i in range(ge.depth)]
+        last = ge.depth - 1
+        k.layernorm_bwd(ws_e.d_ln, xe, f.param_view("norm.weight"), mean_e, rstd_e, None, ws_e.dx[last & 1 ^ 1],
+                        ws_e.dx_act[last & 1 ^ 1], f.grad_view("norm.weight") if need("norm.weight") else None,
+                        f.grad_view("norm.bias") if need("norm.bias") else None,
+                        Ge[last]["mlp.fc2.bias"] if tr_e[last] else None, Me, De)
+        front = need("cls_token") or need("patch_embed.proj.weight") or need("patch_embed.proj.bias")
+        cb_e = (lambda i: sync.block_done("blocks.", i)) if sync is not None else None
+        dx0, _ = BlockStack(k, ge).backward(ws_e, x0, We, Ge, ws_e.dx[last & 1 ^ 1], ws_e.dx_act[last & 1 ^ 1], True, tr_e,
+                                            front, acc_fn, cb_e)
+        if front and dx0 is not None:
+            _EncoderFrontMixin.front_bwd(rt, dx0, cols, ids_keep, B, keep, accumulate, need, False)
+        if sync is not None:
+            sync.backward_done()
+        rt.put_ws(ge, ws_e)
+        rt.put_ws(gd, ws_d)
+        ctx.saved = None
+        grads = [None if (accumulate or not nd) else f.grad_view(n) for n, nd in zip(names, needs)]
+        return (None, None, None, None, None, *grads)
+
+
+# --------------------------------------------------------------------------------------------------
+# public modules
+# --------------------------------------------------------------------------------------------------
+class MaskedAutoencoderViT(nn.Module):
+    """Masked Autoencoder with VisionTransformer backbone (models_mae.py:22-220), HIP-executed."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16,
+                 decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4.0, norm_layer=nn.LayerNorm,
+                 norm_pix_loss=False, precision: Optional[str] = None):
+        super().__init__()
+        eps = self._check_norm(norm_layer)
+        # construction order follows models_mae.py:31-59 so that a given torch seed yields identical weights
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim), requires_grad=False)
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer)
+                                     for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim, bias=True)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, decoder_embed_dim), requires_grad=False)
+        self.decoder_blocks = nn.ModuleList([
+            Block(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer)
+            for _ in range(decoder_depth)])
+        self.decoder_norm = norm_layer(decoder_embed_dim)
+        self.decoder_pred = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
+        self.norm_pix_loss = norm_pix_loss
+        self.initialize_weights()
+        enc = StackGeom(embed_dim, num_heads, depth, int(embed_dim * mlp_ratio))
+        dec = StackGeom(decoder_embed_dim, decoder_num_heads, decoder_depth, int(decoder_embed_dim * mlp_ratio))
+        object.__setattr__(self, "_rt", _Runtime(self, precision or _DEFAULT_PRECISION, enc, dec))
+        self._rt.eps = eps
+
+    @staticmethod
+    def _check_norm(norm_layer):
+        probe = norm_layer(8)
+        if not isinstance(probe, nn.LayerNorm) or not probe.elementwise_affine:
+            raise ValueError("only affine nn.LayerNorm is supported by the HIP path")
+        return float(probe.eps)
+
+    def initialize_weights(self):
+        """models_mae.py:65-82 (same RNG consumption order)."""
+        gs = int(self.patch_embed.num_patches ** 0.5)
+        pos_embed = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], gs, cls_token=True)
+        self.pos_embed.data.copy_(torch.from_numpy(pos_embed).float().unsqueeze(0))
+        dpos = get_2d_sincos_pos_embed(self.decoder_pos_embed.shape[-1], gs, cls_token=True)
+        self.decoder_pos_embed.data.copy_(torch.from_numpy(dpos).float().unsqueeze(0))
+        w = self.patch_embed.proj.weight.data
+        torch.nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        torch.nn.init.normal_(self.cls_token, std=0.02)
+        torch.nn.init.normal_(self.mask_token, std=0.02)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        """models_mae.py:84-93."""
+        if isinstance(m, nn.Linear):
+            torch.nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # pure data-movement helpers kept for API compatibility (models_mae.py:95-121)
+    def patchify(self, imgs):
+        p = self.patch_embed.patch_size[0]
+        assert imgs.shape[2] == imgs.shape[3] and imgs.shape[2] % p == 0
+        h = w = imgs.shape[2] // p
+        x = imgs.reshape(shape=(imgs.shape[0], 3, h, p, w, p))
+        x = torch.einsum("nchpwq->nhwpqc", x)
+        return x.reshape(shape=(imgs.shape[0], h * w, p ** 2 * 3))
+
+    def unpatchify(self, x):
+        p = self.patch_embed.patch_size[0]
+        h = w = int(x.shape[1] ** 0.5)
+        assert h * w == x.shape[1]
+        x = x.reshape(shape=(x.shape[0], h, w, p, p, 3))
+        x = torch.einsum("nhwpqc->nchpwq", x)
+        return x.reshape(shape=(x.shape[0], 3, h * p, h * p))
+
+    def forward(self, imgs, mask_ratio=0.75, noise: Optional[torch.Tensor] = None):
+        """-> (loss, pred [N, L, p*p*3], mask [N, L]).  `noise` replaces torch.rand (models_mae.py:132) for tests."""
+        rt = self._rt
+        rt.ensure(imgs.device)
+        assert imgs.shape[2] == self.patch_embed.img_size[0] and imgs.shape[3] == self.patch_embed.img_size[1]
+        if noise is None:
+            noise = torch.rand(imgs.shape[0], self.patch_embed.num_patches, device=imgs.device)
+        names = rt.flat.names
+        return _MaeFn.apply(rt, imgs, noise, float(mask_ratio), names, *rt.flat.params)
+
+
+def mae_vit_base_patch16_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(patch_size=16, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512,
+                                decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                                norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def mae_vit_large_patch16_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(patch_size=16, embed_dim=1024, depth=24, num_heads=16, decoder_embed_dim=512,
+                                decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                                norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def mae_vit_huge_patch14_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(patch_size=14, embed_dim=1280, depth=32, num_heads=16, decoder_embed_dim=512,
+                                decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                                norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+mae_vit_base_patch16 = mae_vit_base_patch16_dec512d8b
+mae_vit_large_patch16 = mae_vit_large_patch16_dec512d8b
+mae_vit_huge_patch14 = mae_vit_huge_patch14_dec512d8b
+
+
+class _ClassifierBase(nn.Module):
+    def _classify(self, imgs):
+        if self.dense:
+            raise NotImplementedError("dense (DPT decoder) mode is dead code on the reference's path (every caller "
+                                      "passes dense=None, tc.py:5646-5654) and is not built")
+        if self.out_token != "cls":
+            raise NotImplementedError("out_token='spatial' is not on the shipped path (default 'cls', "
+                                      "utils/__init__.py:29,52)")
+        head = self.head if isinstance(self.head, bool) else self.head_bool
+        if not head:
+            raise NotImplementedError("head=False (feature output) is not on the shipped path")
+        rt = self._rt
+        rt.ensure(imgs.device)
+        assert imgs.shape[2] == self.patch_embed.img_size[0] and imgs.shape[3] == self.patch_embed.img_size[1]
+        return _VitClsFn.apply(rt, imgs, rt.flat.names, *rt.flat.params)
+
+
+class ViT_from_MAE(_ClassifierBase):
+    """models.py:143-222: the MAE encoder (decoder deleted) + lin_head.  `.head` is a bool (models.py:177);
+    `decoder_pos_embed` survives in the state dict exactly as in the reference."""
+
+    def __init__(self, weight_path, head, num_classes, frozen, dense, embed_dim, depth, num_heads, out_token,
+                 precision: Optional[str] = None):
+        super().__init__()
+        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        # build the full MAE first (models.py:155-165) so that seeded initialisation matches, then drop the decoder
+        full = MaskedAutoencoderViT(patch_size=16, embed_dim=embed_dim, depth=depth, num_heads=num_heads,
+                                    decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                                    norm_layer=norm_layer)
+        if weight_path is not None:
+            weights = torch.load(weight_path, map_location="cpu")["model"]
+            own = full.state_dict()
+            n = 0
+            for name, param in weights.items():
+                if name in own:
+                    own[name].copy_(param)
+                    n += 1
+            print(f"Successfully loaded params for {n} items")
+        self.patch_embed = full.patch_embed
+        self.cls_token = full.cls_token
+        self.pos_embed = full.pos_embed
+        self.blocks = full.blocks
+        self.norm = full.norm
+        self.decoder_pos_embed = full.decoder_pos_embed
+        self.norm_pix_loss = False
+        self.head = head
+        if head:
+            self.lin_head = nn.Linear(embed_dim, num_classes)
+        self.frozen = frozen
+        self.dense = dense
+        self.out_token = out_token
+        self._learned_pos = False
+        enc = StackGeom(embed_dim, num_heads, depth, int(embed_dim * 4))
+        object.__setattr__(self, "_rt", _Runtime(self, precision or _DEFAULT_PRECISION, enc, None))
+
+    def load_my_state_dict(self, state_dict):
+        own_state = self.state_dict()
+        i = 0
+        for name, param in state_dict.items():
+            if name not in own_state:
+                continue
+            own_state[name].copy_(param)
+            i += 1
+        print(f"Successfully loaded params for {i} items")
+
+    def forward(self, imgs):
+        return self._classify(imgs)
+
+
+class VisionTransformer_from_Any(_ClassifierBase):
+    """models.py:26-140: timm VisionTransformer (learnable pos_embed, trunc-normal init) + lin_head."""
+
+    def __init__(self, head, num_classes, frozen, dense, embed_dim, depth, num_heads, out_token, ImageNet_weights=False,
+                 precision: Optional[str] = None):
+        super().__init__()
+        norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_embed = PatchEmbed(224, 16, 3, embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=0.0)
+        self.blocks = nn.Sequential(*[Block(embed_dim, num_heads, 4.0, qkv_bias=True, norm_layer=norm_layer)
+                                      for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        _timm_head = nn.Linear(embed_dim, 1000)  # consumed RNG like timm's classifier head, replaced below
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+        nn.init.zeros_(_timm_head.weight)  # timm 0.4.12 _init_vit_weights: name.startswith('head') -> zeros
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.zeros_(m.bias)
+                nn.init.ones_(m.weight)
+        if ImageNet_weights:
+            raise NotImplementedError("ImageNet_weights=True downloads an augreg .npz from storage.googleapis.com "
+                                      "(models.py:51-55); load a local checkpoint with load_pretrained() instead")
+        self.head = nn.Identity()
+        self.head_bool = head
+        if head:
+            self.lin_head = nn.Linear(embed_dim, num_classes)
+        self.frozen = frozen
+        self.dense = dense
+        self.out_token = out_token
+        self._learned_pos = True
+        enc = StackGeom(embed_dim, num_heads, depth, int(embed_dim * 4))
+        object.__setattr__(self, "_rt", _Runtime(self, precision or _DEFAULT_PRECISION, enc, None))
+
+    def load_pretrained(self, checkpoint_path):
+        """models.py:68-115 for torch checkpoints (dict with state_dict/model/... or a bare state dict)."""
+        checkpoint = torch.load(str(checkpoint_path), map_location="cpu")
+        state_dict = None
+        if isinstance(checkpoint, dict):
+            for key in ("state_dict", "model", "model_state", "weights", "params"):
+                if isinstance(checkpoint.get(key), dict):
+                    state_dict = checkpoint[key]
+                    break
+            if state_dict is None and all(isinstance(k, str) for k in checkpoint.keys()):
+                state_dict = checkpoint
+        if not isinstance(state_dict, dict):
+            print(f"Warning: unsupported checkpoint format for {checkpoint_path!s}: {type(checkpoint)}")
+            return
+        missing, unexpected = self.load_state_dict(state_dict, strict=False)
+        if missing:
+            print(f"Missing keys when loading pretrained weights: {missing}")
+        if unexpected:
+            print(f"Unexpected keys when loading pretrained weights: {unexpected}")
+
+    def forward(self, x):
+        return self._classify(x)
+
+
+# factories with the reference's names / signatures (src/ssl4polyp/utils/__init__.py:29-67)
+def get_MAE_backbone(weight_path, head, num_classes, frozen, dense, out_token="cls", precision=None):
+    return ViT_from_MAE(weight_path, head, num_classes, frozen, dense, embed_dim=768, depth=12, num_heads=12,
+                        out_token=out_token, precision=precision)
+
+
+def get_ImageNet_or_random_ViT(head, num_classes, frozen, dense, ImageNet_weights, out_token="cls", precision=None):
+    return VisionTransformer_from_Any(head, num_classes, frozen, dense, 768, 12, 12, out_token, ImageNet_weights,
+                                      precision=precision)

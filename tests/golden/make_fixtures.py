@@ -246,9 +246,9 @@ def main():
 
     # ---------------- tiny classifiers ----------------
     tiny_cls = {}
-    ccfg = O.ViTConfig(embed_dim=64, depth=2, num_heads=4)  # img 224 / patch 16 are fixed by models.py:155-165
+    ccfg = O.ViTConfig(embed_dim=64, depth=2, num_heads=2)  # img 224 / patch 16 are fixed by models.py:155-165
     torch.manual_seed(13)
-    vm = ref_models.ViT_from_MAE(None, True, 2, False, None, embed_dim=64, depth=2, num_heads=4, out_token="cls")
+    vm = ref_models.ViT_from_MAE(None, True, 2, False, None, embed_dim=64, depth=2, num_heads=2, out_token="cls")
     g = torch.Generator().manual_seed(14)
     with torch.no_grad():
         for n, p in vm.named_parameters():
@@ -270,7 +270,7 @@ def main():
     assert vm.head is True and not isinstance(vm.head, nn.Module)  # models.py:177 quirk
 
     torch.manual_seed(15)
-    va = ref_models.VisionTransformer_from_Any(True, 2, False, None, 64, 2, 4, "cls", False)
+    va = ref_models.VisionTransformer_from_Any(True, 2, False, None, 64, 2, 2, "cls", False)
     with torch.no_grad():
         for n, p in va.named_parameters():
             if p.ndim == 1:

@@ -1,0 +1,381 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point against a plain PyTorch fp32 reference of the
+same op on identical seeded inputs (bf16 mode: inputs pre-rounded to bf16, so the only differences are
+accumulation order and the documented roundings).  Run with `pytest -m gpu` on the GPU box."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _k(precision):
+    from ssl4polyp_amd.engine import Kernels
+    return Kernels(precision)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    from ssl4polyp_amd import _lib
+    _lib.load()
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,D", [(37, 768), (50, 512), (13, 64), (7, 32), (2000, 768)])
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_layernorm_fwd_bwd(M, D, prec):
+    k = _k(prec)
+    x = rnd(M, D, seed=1, scale=2.0) + 0.5
+    gamma, beta = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    y = torch.empty(M, D, dtype=k.act_dtype, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    k.layernorm_fwd(x, gamma, beta, y, mean, rstd, M, D)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), gr, br, 1e-6)
+    tol = 8e-3 if prec == "bf16" else 2e-6
+    assert rel(y.float(), yr) < tol
+    assert rel(mean, x.mean(1)) < 1e-5
+    dy = rnd(M, D, seed=4).to(k.act_dtype)
+    dres = rnd(M, D, seed=5)
+    yr.backward(dy.float())
+    dx, dx_act = torch.empty(M, D, device=DEV), torch.empty(M, D, dtype=k.act_dtype, device=DEV)
+    dg, db, dc = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    k.layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, dx_act, dg, db, dc, M, D)
+    want = xr.grad + dres
+    assert rel(dx, want) < 1e-5
+    assert rel(dx_act.float(), want) < tol
+    assert rel(dg, gr.grad) < 2e-5
+    assert rel(db, br.grad) < 2e-5
+    assert rel(dc, want.sum(0)) < 2e-5
+    # in-place residual (dres aliases dx), no optional outputs
+    dx2 = dres.clone()
+    k.layernorm_bwd(dy, x, gamma, mean, rstd, dx2, dx2, None, None, None, None, M, D)
+    assert rel(dx2, want) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(200, 264, 136), (1000, 768, 768), (256, 128, 64), (34, 96, 32), (394, 3072, 768), (394, 768, 3072),
+               (129, 8, 520)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_gemm_layouts(M, N, K, layout, prec):
+    k = _k(prec)
+    dt = k.act_dtype
+    epc = 8 if prec == "bf16" else 4
+    if layout in ("tn",) and (M % epc):
+        pytest.skip("k-major A needs M % chunk == 0")
+    if layout in ("nn", "tn") and (N % epc):
+        pytest.skip("k-major B needs N % chunk == 0")
+    A = rnd(M, K, seed=10).to(dt)
+    B = rnd(N, K, seed=11).to(dt)
+    want = A.float() @ B.float().t()
+    bias = rnd(N, seed=12)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    a_mat, lda, akm = (A, K, 0) if layout != "tn" else (A.t().contiguous(), M, 1)
+    b_mat, ldb, bkm = (B, K, 0) if layout == "nt" else (B.t().contiguous(), N, 1)
+    from ssl4polyp_amd._lib import EPI_STORE
+    k.gemm(a_mat, lda, akm, b_mat, ldb, bkm, bias, C, N, EPI_STORE, M, N, K)
+    tol = 2e-5 if prec == "bf16" else 2e-6
+    assert rel(C, want + bias) < tol * math.sqrt(K / 32)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_gemm_epilogues(prec):
+    from ssl4polyp_amd._lib import EPI_ACCUM, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, EPI_STORE
+    k = _k(prec)
+    dt = k.act_dtype
+    M, N, K = 197 * 2, 256, 192
+    A, B = rnd(M, K, seed=20).to(dt), rnd(N, K, seed=21, scale=0.2).to(dt)
+    bias = rnd(N, seed=22)
+    acc = A.float() @ B.float().t()
+    tolc = 1e-2 if prec == "bf16" else 3e-6
+    # act-typed plain store
+    C = torch.empty(M, N, dtype=dt, device=DEV)
+    k.gemm(A, K, 0, B, K, 0, bias, C, N, EPI_STORE, M, N, K)
+    assert rel(C.float(), acc + bias) < tolc
+    # GELU: aux = pre-activation, C = gelu(pre as stored)
+    aux = torch.empty(M, N, dtype=dt, device=DEV)
+    k.gemm(A, K, 0, B, K, 0, bias, C, N, EPI_GELU, M, N, K, aux=aux)
+    assert rel(aux.float(), acc + bias) < tolc
+    assert rel(C.float(), F.gelu(aux.float())) < tolc
+    # residual, out of place and in place
+    resid = rnd(M, N, seed=23)
+    out = torch.empty(M, N, device=DEV)
+    k.gemm(A, K, 0, B, K, 0, bias, out, N, EPI_RESIDUAL, M, N, K, resid=resid)
+    assert rel(out, resid + acc + bias) < 1e-5
+    r2 = resid.clone()
+    k.gemm(A, K, 0, B, K, 0, bias, r2, N, EPI_RESIDUAL, M, N, K, resid=r2)
+    assert rel(r2, resid + acc + bias) < 1e-5
+    # dGELU
+    pre = rnd(M, N, seed=24).to(dt)
+    k.gemm(A, K, 0, B, K, 0, None, C, N, EPI_DGELU, M, N, K, aux=pre)
+    p32 = pre.float().requires_grad_(True)
+    F.gelu(p32).backward(acc)
+    assert rel(C.float(), p32.grad) < tolc
+    # accumulate
+    base = rnd(M, N, seed=25)
+    b2 = base.clone()
+    k.gemm(A, K, 0, B, K, 0, None, b2, N, EPI_ACCUM, M, N, K)
+    assert rel(b2, base + acc) < 1e-5
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_linear_helpers_match_autograd(prec):
+    """linear_fwd / linear_dgrad / linear_wgrad == nn.Linear forward + backward."""
+    k = _k(prec)
+    dt = k.act_dtype
+    M, K, N = 394, 192, 320
+    x, W = rnd(M, K, seed=30).to(dt), rnd(N, K, seed=31, scale=0.1).to(dt)
+    dy = rnd(M, N, seed=32).to(dt)
+    xr, Wr = x.float().requires_grad_(True), W.float().requires_grad_(True)
+    (xr @ Wr.t()).backward(dy.float())
+    dx = torch.empty(M, K, device=DEV)
+    k.linear_dgrad(dy, W, dx, M, N, K)
+    assert rel(dx, xr.grad) < 1e-4
+    dW = torch.empty(N, K, device=DEV)
+    k.linear_wgrad(dy, x, dW, M, N, K, False)
+    assert rel(dW, Wr.grad) < 1e-4
+    k.linear_wgrad(dy, x, dW, M, N, K, True)
+    assert rel(dW, 2 * Wr.grad) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, B, N, H, dh):
+    q, k_, v = qkv.float().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    s = (q @ k_.transpose(-2, -1)) * dh ** -0.5
+    lse = torch.logsumexp(s, dim=-1)
+    o = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, N, H * dh)
+    return o, lse
+
+
+@pytest.mark.parametrize("B,N,H,dh", [(2, 197, 3, 64), (3, 50, 2, 64), (2, 197, 4, 32), (2, 17, 2, 32), (1, 33, 1, 64),
+                                      (1, 224, 1, 32)])
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_attention_fwd_bwd(B, N, H, dh, prec):
+    k = _k(prec)
+    dt = k.act_dtype
+    D = H * dh
+    qkv = rnd(B, N, 3 * D, seed=40, scale=1.5).to(dt)
+    out = torch.full((B, N, D), float("nan"), dtype=dt, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+    k.attention_fwd(qkv, out, lse, B, N, H, dh)
+    qr = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, B, N, H, dh)
+    tol = 1.5e-2 if prec == "bf16" else 2e-5
+    assert rel(out.float(), o_ref) < tol
+    assert rel(lse, lse_ref) < 1e-5
+    dout = rnd(B, N, D, seed=41).to(dt)
+    o_ref.backward(dout.float())
+    dqkv = torch.full((B, N, 3 * D), float("nan"), dtype=dt, device=DEV)
+    delta = torch.empty(B, H, N, device=DEV)
+    k.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, dh)
+    got, want = dqkv.float().reshape(B, N, 3, D), qr.grad.reshape(B, N, 3, D)
+    for j, nm in enumerate("qkv"):
+        assert rel(got[:, :, j], want[:, :, j]) < (3e-2 if prec == "bf16" else 5e-5), nm
+
+
+def test_attention_softmax_spike():
+    """One dominant key per query (large logits): exercises the max-subtraction path."""
+    k = _k("fp32")
+    B, N, H, dh = 1, 197, 2, 64
+    qkv = rnd(B, N, 3 * H * dh, seed=42)
+    qkv[:, :, : 2 * H * dh] *= 6.0
+    out, lse = torch.empty(B, N, H * dh, device=DEV), torch.empty(B, H, N, device=DEV)
+    k.attention_fwd(qkv, out, lse, B, N, H, dh)
+    o_ref, lse_ref = _attn_ref(qkv, B, N, H, dh)
+    assert torch.isfinite(out).all()
+    assert rel(out, o_ref) < 1e-4 and rel(lse, lse_ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_colsum_cast_gradstats(prec):
+    from ssl4polyp_amd import _lib
+    from ssl4polyp_amd.engine import _ptr, _stream
+    k = _k(prec)
+    x = rnd(777, 520, seed=50).to(k.act_dtype)
+    out = torch.ones(520, device=DEV)
+    k.colsum(x, out, 777, 520)
+    assert rel(out, 1 + x.float().sum(0)) < 1e-5
+    src = rnd(1027, seed=51)
+    dst = torch.empty(1027, dtype=k.act_dtype, device=DEV)
+    k.cast(src, dst)
+    assert torch.equal(dst, src.to(k.act_dtype))
+    g = rnd(100003, seed=52)
+    g[17], g[99], g[100002] = float("nan"), float("inf"), float("-inf")
+    stats = torch.zeros(3, device=DEV)
+    _lib.check(k.lib.pm_grad_stats(_ptr(g), g.numel(), _ptr(stats), _stream()), "pm_grad_stats")
+    assert stats[1].item() == 1 and stats[2].item() == 2
+    g2 = rnd(4097, seed=53)
+    stats.zero_()
+    _lib.check(k.lib.pm_grad_stats(_ptr(g2), g2.numel(), _ptr(stats), _stream()), "pm_grad_stats")
+    assert abs(stats[0].item() - (g2.double() ** 2).sum().item()) < 1e-3 * stats[0].item()
+
+
+@pytest.mark.parametrize("img,p,D", [(224, 16, 768), (32, 8, 64)])
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_patch_embed_path(img, p, D, prec):
+    """im2col (+kept-patch gather) + GEMM + token assembly == Conv2d patch embed + pos + cls (+ gather)."""
+    from ssl4polyp_amd import _lib
+    from ssl4polyp_amd.engine import _ptr, _stream
+    k = _k(prec)
+    B, C = 3, 3
+    L = (img // p) ** 2
+    keep = L // 4
+    imgs = rnd(B, C, img, img, seed=60)
+    W = rnd(D, C, p, p, seed=61, scale=0.05)
+    bias, cls, pos = rnd(D, seed=62), rnd(D, seed=63), rnd(L + 1, D, seed=64)
+    ref = F.conv2d(imgs.to(k.act_dtype).float(), W.to(k.act_dtype).float(), bias, stride=p).flatten(2).transpose(1, 2)
+    ref = ref + pos[1:]
+    g = torch.Generator().manual_seed(65)
+    ids = torch.stack([torch.randperm(L, generator=g)[:keep] for _ in range(B)]).to(DEV)
+    for ids_keep, kp in ((None, L), (ids.int().contiguous(), keep)):
+        cols = torch.empty(B * kp, C * p * p, dtype=k.act_dtype, device=DEV)
+        _lib.check(k.lib.pm_patch_im2col(_ptr(imgs), _ptr(ids_keep), _ptr(cols), k.act, B, C, img, p, kp, _stream()), "im2col")
+        emb = torch.empty(B * kp, D, device=DEV)
+        k.linear_fwd(cols, W.to(k.act_dtype).view(D, -1), bias, emb, B * kp, D, C * p * p)
+        x = torch.empty(B, kp + 1, D, device=DEV)
+        _lib.check(k.lib.pm_assemble_tokens(_ptr(emb), _ptr(cls), _ptr(pos), _ptr(ids_keep), _ptr(x), B, kp, D, _stream()), "assemble")
+        want = ref if ids_keep is None else torch.gather(ref, 1, ids.unsqueeze(-1).expand(-1, -1, D))
+        want = torch.cat([(cls + pos[0]).expand(B, 1, D), want], 1)
+        assert rel(x, want) < 2e-5
+        # backward of the assembly
+        dx = rnd(B, kp + 1, D, seed=66)
+        demb = torch.empty(B * kp, D, dtype=k.act_dtype, device=DEV)
+        dcls, dpos = torch.zeros(D, device=DEV), torch.zeros(L + 1, D, device=DEV)
+        _lib.check(k.lib.pm_assemble_tokens_bwd(_ptr(dx), _ptr(ids_keep), _ptr(demb), k.act, _ptr(dcls), _ptr(dpos), B, kp, D,
+                                                _stream()), "assemble_bwd")
+        assert torch.equal(demb.view(B, kp, D), dx[:, 1:].to(k.act_dtype))
+        assert rel(dcls, dx[:, 0].sum(0)) < 1e-5
+        want_pos = torch.zeros(L + 1, D, device=DEV)
+        want_pos[0] = dx[:, 0].sum(0)
+        idx = torch.arange(L, device=DEV).expand(B, L) if ids_keep is None else ids
+        want_pos.index_add_(0, (idx + 1).reshape(-1), dx[:, 1:].reshape(-1, D))
+        assert rel(dpos, want_pos) < 1e-5
+
+
+def test_mae_masking_and_unshuffle():
+    from ssl4polyp_amd import _lib
+    from ssl4polyp_amd.engine import _ptr, _stream
+    k = _k("bf16")
+    B, L, keep, D = 5, 196, 49, 512
+    noise = torch.rand(B, L, generator=torch.Generator().manual_seed(70)).to(DEV)
+    noise[0, 5] = noise[0, 100]  # a tie: stable order must win
+    ids_shuffle = torch.empty(B, L, dtype=torch.int32, device=DEV)
+    ids_restore = torch.empty(B, L, dtype=torch.int32, device=DEV)
+    mask = torch.empty(B, L, device=DEV)
+    _lib.check(k.lib.pm_mae_masking(_ptr(noise), _ptr(ids_shuffle), _ptr(ids_restore), _ptr(mask), B, L, keep, _stream()), "masking")
+    s_ref = torch.argsort(noise.cpu(), dim=1, stable=True)
+    r_ref = torch.argsort(s_ref, dim=1)
+    assert torch.equal(ids_shuffle.cpu().long(), s_ref) and torch.equal(ids_restore.cpu().long(), r_ref)
+    m_ref = torch.ones(B, L)
+    m_ref[:, :keep] = 0
+    assert torch.equal(mask.cpu(), torch.gather(m_ref, 1, r_ref))
+    emb, mtok, dpos = rnd(B, keep + 1, D, seed=71), rnd(D, seed=72), rnd(L + 1, D, seed=73)
+    out = torch.empty(B, L + 1, D, device=DEV)
+    _lib.check(k.lib.pm_mae_unshuffle(_ptr(emb), _ptr(mtok), _ptr(dpos), _ptr(ids_restore), _ptr(out), B, L, keep, D, _stream()), "unshuffle")
+    er = emb.clone().requires_grad_(True)
+    mr = mtok.clone().requires_grad_(True)
+    x_ = torch.cat([er[:, 1:], mr.expand(B, L - keep, D)], 1)
+    x_ = torch.gather(x_, 1, ids_restore.long().unsqueeze(-1).expand(-1, -1, D))
+    want = torch.cat([er[:, :1], x_], 1) + dpos
+    assert rel(out, want) < 1e-6
+    dout = rnd(B, L + 1, D, seed=74)
+    want.backward(dout)
+    demb = torch.empty(B, keep + 1, D, device=DEV)
+    dm = torch.zeros(D, device=DEV)
+    _lib.check(k.lib.pm_mae_unshuffle_bwd(_ptr(dout), _ptr(ids_shuffle), _ptr(demb), 0, _ptr(dm), B, L, keep, D, _stream()), "unshuffle_bwd")
+    assert rel(demb, er.grad) < 1e-6 and rel(dm, mr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("norm_pix", [0, 1])
+@pytest.mark.parametrize("img,p", [(224, 16), (32, 8)])
+def test_mae_loss(norm_pix, img, p):
+    from oracle import vit_mae_ref as O
+    from ssl4polyp_amd import _lib
+    from ssl4polyp_amd.engine import _ptr, _stream
+    k = _k("fp32")
+    B, C = 3, 3
+    L, PE = (img // p) ** 2, p * p * C
+    imgs = rnd(B, C, img, img, seed=80)
+    pred_full = rnd(B, L + 1, PE, seed=81)
+    mask = (torch.rand(B, L, generator=torch.Generator().manual_seed(82)) < 0.75).float().to(DEV)
+    pl = torch.empty(B * L, device=DEV)
+    sums, loss = torch.empty(2, device=DEV), torch.empty(1, device=DEV)
+    _lib.check(k.lib.pm_mae_loss_fwd(_ptr(imgs), _ptr(pred_full), PE, 1, _ptr(pl), B, C, img, p, norm_pix, _stream()), "loss_fwd")
+    _lib.check(k.lib.pm_mae_loss_finish(_ptr(pl), _ptr(mask), B * L, _ptr(sums), _ptr(loss), _stream()), "loss_finish")
+    cfg = O.ViTConfig(img_size=img, patch_size=p)
+    pr = pred_full[:, 1:].cpu().clone().requires_grad_(True)
+    want = O.mae_loss(imgs.cpu(), pr, mask.cpu(), cfg, bool(norm_pix))
+    assert abs(loss.item() - want.item()) < 2e-6 * abs(want.item())
+    want.backward()
+    dpred = torch.full((B, L + 1, PE), float("nan"), device=DEV)
+    dl = torch.full((1,), 0.5, device=DEV)
+    _lib.check(k.lib.pm_mae_loss_bwd(_ptr(imgs), _ptr(pred_full), PE, 1, _ptr(mask), _ptr(sums), _ptr(dl), _ptr(dpred), 0, B, C,
+                                     img, p, norm_pix, _stream()), "loss_bwd")
+    assert torch.equal(dpred[:, 0], torch.zeros(B, PE, device=DEV))
+    assert rel(dpred[:, 1:], 0.5 * pr.grad) < 1e-5
+
+
+def test_cls_head_and_adamw():
+    from ssl4polyp_amd import _lib
+    from ssl4polyp_amd.engine import _ptr, _stream
+    k = _k("bf16")
+    B, N, D, nc = 5, 197, 768, 2
+    x = rnd(B, N, D, seed=90)
+    gamma, beta = 1 + 0.1 * rnd(D, seed=91), 0.1 * rnd(D, seed=92)
+    W, bias = rnd(nc, D, seed=93, scale=0.05), rnd(nc, seed=94)
+    xn, mean, rstd = torch.empty(B, D, device=DEV), torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    logits = torch.empty(B, nc, device=DEV)
+    _lib.check(k.lib.pm_cls_head_fwd(_ptr(x), N, _ptr(gamma), _ptr(beta), _ptr(W), _ptr(bias), _ptr(xn), _ptr(mean), _ptr(rstd),
+                                     _ptr(logits), B, D, nc, 1e-6, _stream()), "cls_head_fwd")
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    Wr, bbr = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = F.linear(F.layer_norm(xr, (D,), gr, br, 1e-6)[:, 0], Wr, bbr)
+    assert rel(logits, ref) < 1e-5
+    dlog = rnd(B, nc, seed=95)
+    ref.backward(dlog)
+    dx = torch.full((B, N, D), float("nan"), device=DEV)
+    dxa = torch.empty(B, N, D, dtype=torch.bfloat16, device=DEV)
+    dW, dbias = torch.zeros(nc, D, device=DEV), torch.zeros(nc, device=DEV)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    _lib.check(k.lib.pm_cls_head_bwd(_ptr(dlog), _ptr(x), N, _ptr(gamma), _ptr(W), _ptr(xn), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                     _ptr(dxa), 1, _ptr(dW), _ptr(dbias), _ptr(dg), _ptr(db), B, D, nc, _stream()), "cls_head_bwd")
+    assert rel(dx, xr.grad) < 1e-5 and rel(dW, Wr.grad) < 1e-5 and rel(dbias, bbr.grad) < 1e-5
+    assert rel(dg, gr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
+    assert rel(dxa.float(), xr.grad) < 8e-3
+    # AdamW, 3 steps, against torch.optim.AdamW
+    n = 4096 + 64
+    p0, p1 = rnd(n, seed=96), None
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    p1, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in range(1, 4):
+        g = rnd(n, seed=100 + step)
+        pt.grad = g.clone()
+        opt.step()
+        _lib.check(k.lib.pm_adamw(_ptr(p1), _ptr(g), _ptr(m), _ptr(v), _ptr(shadow), 1, n, 1e-2, 0.9, 0.95, 1e-8, 0.05, step, 1.0,
+                                  _stream()), "adamw")
+    assert rel(p1, pt.detach()) < 2e-6
+    assert torch.equal(shadow, p1.bfloat16())

@@ -53,7 +53,7 @@ def test_tiny_mae_forward_and_grads(golden):
 
 def test_tiny_classifiers(golden):
     fx = golden("tiny_cls.npz")
-    cfg = O.ViTConfig(embed_dim=64, depth=2, num_heads=4)
+    cfg = O.ViTConfig(embed_dim=64, depth=2, num_heads=2)
     imgs, labels = torch.from_numpy(fx["imgs"]), torch.from_numpy(fx["labels"])
     sd = _sd(fx, "mae/w/")
     assert "decoder_pos_embed" in sd  # survives `del` of the decoder (models.py:171-175)
