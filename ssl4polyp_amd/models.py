@@ -211,7 +211,7 @@ class _VitClsFn(torch.autograd.Function):
         L = mod.patch_embed.num_patches
         N = L + 1
         D = g.dim
-        training = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        training = any(ctx.needs_input_grad)  # (grad mode is already off inside Function.forward)
         imgs = imgs.contiguous().float()
         cols, x0 = _EncoderFrontMixin.front_fwd(rt, imgs, None, L)
         ws = rt.get_ws(g, B, N, training)
@@ -294,7 +294,7 @@ class _MaeFn(torch.autograd.Function):
         De, Dd, PE = ge.dim, gd.dim, p * p * C
         dev = imgs.device
         f32 = torch.float32
-        training = torch.is_grad_enabled() and any(q.requires_grad for q in params)
+        training = any(ctx.needs_input_grad)  # (grad mode is already off inside Function.forward)
         imgs = imgs.contiguous().float()
         ctx.set_materialize_grads(False)
         # -- masking (models_mae.py:123-148)

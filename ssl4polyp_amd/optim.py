@@ -1,0 +1,159 @@
+"""Fused AdamW + gradient statistics over the engine's flat parameter storage.
+
+Same update rule and hyper-parameter surface as ``torch.optim.AdamW`` as the reference uses it
+(train_classification.py:5766-5768: two groups head/backbone, default betas; mae/main_pretrain.py:217-218:
+decay / no-decay groups from timm ``add_weight_decay``, betas (0.9, 0.95)), but one HIP launch per
+contiguous flat segment instead of ~150 tensors, and the same launch refreshes the bf16 shadow weights the
+MFMA GEMMs read.  ``grad_stats`` replaces the per-parameter host-synchronising loops of
+train_classification.py:1437-1454 (_compute_grad_norm) and mae/util/misc.py:387-400 (detect_grad_anomalies)
+with one pass that stays on the device.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional
+
+import torch
+
+from . import _lib
+from .engine import _ptr, _stream
+
+
+def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
+    """timm 0.4.12 optim_factory.add_weight_decay (main_pretrain.py:217): 1-D params and biases get no decay."""
+    decay, no_decay = [], []
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if len(param.shape) == 1 or name.endswith(".bias") or name in skip_list:
+            no_decay.append(param)
+        else:
+            decay.append(param)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, model, params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        """`model`: an ssl4polyp_amd module (owns the flat storage).  `params`: iterable of parameters or of
+        torch-style param-group dicts (default: all parameters of the model)."""
+        self._rt = model._rt
+        if params is None:
+            params = list(model.parameters())
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._M: Dict[str, torch.Tensor] = {}
+        self._V: Dict[str, torch.Tensor] = {}
+        self._plan = None
+        self._plan_key = None
+        self.grad_scale = 1.0  # e.g. 1/world_size when gradients were all-reduced with SUM
+        self.grad_sync = None  # parallel.GradSync: waited on before the update
+
+    # -- planning: contiguous flat segments per group --------------------------------------------
+    def _ensure_state(self):
+        f = self._rt.flat
+        if f is None or not f.P:
+            raise _lib.PolypMaeError("FusedAdamW: run a forward pass (or model._rt.ensure(device)) before step()")
+        key = (id(f.P["mat"]), id(f.P["vec"]))
+        if self._plan_key != key:
+            old_M, old_V = self._M, self._V
+            self._M = {r: torch.zeros_like(t) for r, t in f.P.items()}
+            self._V = {r: torch.zeros_like(t) for r, t in f.P.items()}
+            for r in old_M:  # re-materialised storage: carry the moments over
+                if old_M[r].numel() == self._M[r].numel():
+                    self._M[r].copy_(old_M[r])
+                    self._V[r].copy_(old_V[r])
+            self._plan_key = key
+            self._plan = None
+        return f
+
+    def _segments(self, f, group):
+        """[(region, lo, hi)] covering the group's parameters that currently have a gradient."""
+        idx = {id(p): i for i, p in enumerate(f.params)}
+        items = []
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            i = idx.get(id(p))
+            if i is None:
+                raise _lib.PolypMaeError("FusedAdamW: parameter does not belong to the model's flat storage")
+            if not f.grad_is_flat(f.names[i]):  # foreign gradient tensor: stage it into the flat range
+                f.grad_view(f.names[i]).copy_(p.grad)
+            A = f.ALIGN
+            items.append((f.region[i], f.offset[i], f.offset[i] + (f.numel[i] + A - 1) // A * A))
+        items.sort()
+        segs = []
+        for r, lo, hi in items:
+            if segs and segs[-1][0] == r and segs[-1][2] == lo:
+                segs[-1] = (r, segs[-1][1], hi)
+            else:
+                segs.append((r, lo, hi))
+        return segs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        f = self._ensure_state()
+        if self.grad_sync is not None:
+            self.grad_sync.wait()
+        lib = self._rt.k.lib
+        for group in self.param_groups:
+            group["step"] = int(group.get("step", 0)) + 1
+            b1, b2 = group["betas"]
+            for r, lo, hi in self._segments(f, group):
+                shadow = f.S[lo:hi] if (r == "mat" and f.S is not None) else None
+                _lib.check(lib.pm_adamw(_ptr(f.P[r][lo:hi]), _ptr(f.G[r][lo:hi]), _ptr(self._M[r][lo:hi]),
+                                        _ptr(self._V[r][lo:hi]), _ptr(shadow),
+                                        _lib.dtype_code(shadow.dtype) if shadow is not None else 0, hi - lo,
+                                        float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                        float(group["weight_decay"]), group["step"], float(self.grad_scale), _stream()),
+                           "pm_adamw")
+        return loss
+
+    def grad_stats(self) -> torch.Tensor:
+        """Device tensor [sum(g^2), #NaN, #Inf] over every gradient of every group (no host sync)."""
+        f = self._ensure_state()
+        out = torch.zeros(3, dtype=torch.float32, device=f.device)
+        lib = self._rt.k.lib
+        for group in self.param_groups:
+            for r, lo, hi in self._segments(f, group):
+                _lib.check(lib.pm_grad_stats(_ptr(f.G[r][lo:hi]), hi - lo, _ptr(out), _stream()), "pm_grad_stats")
+        return out
+
+    # -- torch.optim.AdamW-compatible (de)serialisation --------------------------------------------
+    def state_dict(self):
+        f = self._rt.flat
+        idx = {id(p): i for i, p in enumerate(f.params)} if f is not None else {}
+        state, groups, k = {}, [], 0
+        for group in self.param_groups:
+            ids = []
+            for p in group["params"]:
+                i = idx.get(id(p))
+                if i is not None and self._M:
+                    r, lo, n = f.region[i], f.offset[i], f.numel[i]
+                    state[k] = {"step": torch.tensor(float(group.get("step", 0))),
+                                "exp_avg": self._M[r][lo:lo + n].view(p.shape).clone(),
+                                "exp_avg_sq": self._V[r][lo:lo + n].view(p.shape).clone()}
+                ids.append(k)
+                k += 1
+            g = {kk: v for kk, v in group.items() if kk != "params"}
+            g["params"] = ids
+            groups.append(g)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        f = self._ensure_state()
+        idx = {id(p): i for i, p in enumerate(f.params)}
+        for group, saved in zip(self.param_groups, sd["param_groups"]):
+            for kk, v in saved.items():
+                if kk != "params":
+                    group[kk] = v
+            for p, k in zip(group["params"], saved["params"]):
+                st = sd["state"].get(k)
+                if st is None:
+                    continue
+                i = idx[id(p)]
+                r, lo, n = f.region[i], f.offset[i], f.numel[i]
+                self._M[r][lo:lo + n].copy_(st["exp_avg"].reshape(-1))
+                self._V[r][lo:lo + n].copy_(st["exp_avg_sq"].reshape(-1))
+                group["step"] = int(float(st["step"]))
