@@ -51,10 +51,13 @@ int pm_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* 
  *   dx_f32[M,D] (ld ldx) = (dres ? dres : 0) + LN_bwd(dy);  dx_act (optional) = cast(dx_f32)
  *   dgamma += sum_m dy*xhat ; dbeta += sum_m dy ; dcolsum (optional) += sum_m dx   (bias grad of the
  *   Linear whose output was added into this residual stream).  The three accumulators must be
- *   zero-initialised (or hold the running gradient) by the caller. */
+ *   zero-initialised (or hold the running gradient) by the caller.  `workspace` (>= 512*3*D*4 bytes, optional):
+ *   per-block partial column sums, reduced in a fixed order by a second launch; without it the sums use
+ *   float atomics (order-dependent rounding). */
 int pm_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma, const float* mean,
                      const float* rstd, const float* dres, long lddres, float* dx, long lddx, void* dx_act,
-                     int act_dtype, float* dgamma, float* dbeta, float* dcolsum, int M, int D, void* stream);
+                     int act_dtype, float* dgamma, float* dbeta, float* dcolsum, int M, int D, void* workspace,
+                     size_t ws_bytes, void* stream);
 
 /* General matrix product with fused epilogue -- replaces every nn.Linear / Conv2d-as-GEMM of the path
  * and their dgrad / wgrad.   acc[M,N] = sum_k A(m,k) * B(n,k)
@@ -66,6 +69,13 @@ int pm_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, con
 int pm_gemm(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
             const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
             int M, int N, int K, void* stream);
+
+/* Same as pm_gemm with a caller-owned scratch buffer: when the output has few 128x128 tiles and K is long (the wgrad
+ * shapes: K = number of tokens) the k-loop is split over up to 16 blocks per tile, partial sums go to f32 slabs in
+ * `workspace` and are reduced in a fixed order (deterministic).  ws_bytes >= 16*M*N*4 enables every split. */
+int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
+               const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
+               int M, int N, int K, void* workspace, size_t ws_bytes, void* stream);
 
 /* Fused multi-head self-attention core -- replaces timm Attention.forward between qkv and proj:
  * softmax(q k^T * dh^-0.5) v, never materialising the [N,N] scores in HBM.

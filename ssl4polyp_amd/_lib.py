@@ -20,8 +20,9 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 # name -> argtypes, exactly the prototypes of include/polypmae.h
 SIGNATURES = {
     "pm_layernorm_fwd": [P, L, P, P, P, I, P, P, I, I, F, P],
-    "pm_layernorm_bwd": [P, I, P, L, P, P, P, P, L, P, L, P, I, P, P, P, I, I, P],
+    "pm_layernorm_bwd": [P, I, P, L, P, P, P, P, L, P, L, P, I, P, P, P, I, I, P, ctypes.c_size_t, P],
     "pm_gemm": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P],
+    "pm_gemm_ws": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P],
     "pm_attention_fwd": [P, P, P, I, I, I, I, I, P],
     "pm_attention_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "pm_colsum": [P, L, I, P, I, I, P],

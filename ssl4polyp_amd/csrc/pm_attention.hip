@@ -129,7 +129,8 @@ __device__ __forceinline__ void store_tile_T(T* __restrict__ rowptr, bool valid,
 
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <int NT> struct Waves { static constexpr int value = NT >= 4 ? 4 : NT; };
+// one wave per 32-row tile (7 waves for N = 197): every wave does identical work, nothing idles on a tail tile
+template <int NT> struct Waves { static constexpr int value = NT; };
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -159,40 +160,48 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_fwd_kernel(const T
     Frag16 fq[KS];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) fq[kk] = frag_global<T>(base + (long)q * ld, qv, kk, lane);
-    f32x16 s[NT];
-    float mx = -INFINITY;
+    // online softmax over the key tiles: running max m (shared by the two lane halves of a query), running
+    // sum l, O^T rescaled by exp2((m_old - m_new) c) -- only 16 score registers are live at a time.
+    f32x16 o[DT];
 #pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
+    float m = -INFINITY, l = 0.f;
+#pragma unroll 1
     for (int kt = 0; kt < NT; ++kt) {
-      s[kt] = zero16();
+      f32x16 s = zero16();
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) s[kt] = mfma16B<T>(frag_rows<T, DH>(imgK, kt * 32, kk, lane), fq[kk], s[kt]);
+      for (int kk = 0; kk < KS; ++kk) s = mfma16B<T>(frag_rows<T, DH>(imgK, kt * 32, kk, lane), fq[kk], s);
+      float tm = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kt * 32 + acc_row(r, hh);
-        s[kt][r] = key < N ? s[kt][r] : -INFINITY;
-        mx = fmaxf(mx, s[kt][r]);
+        s[r] = key < N ? s[r] : -INFINITY;
+        tm = fmaxf(tm, s[r]);
       }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+      tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+      const float mn = fmaxf(m, tm);  // finite from the first tile on (key 0 is always valid)
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+      float ts = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[kt][r] = __builtin_amdgcn_exp2f((s[kt][r] - mx) * c);
-        sum += s[kt][r];
+        s[r] = __builtin_amdgcn_exp2f((s[r] - mn) * c);
+        ts += s[r];
       }
-    sum += __shfl_xor(sum, 32, 64);
-    if (qv && hh == 0) lse[((long)b * H + h) * N + q] = mx * scale + __logf(sum);
-    const float inv = 1.0f / sum;
+      l = l * alpha + ts;
+      m = mn;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        o[dt] = mma_imgT_acc<T, DH>(imgV, kt * 32, dt * 32, s, o[dt], lane);
+      }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (qv && hh == 0) lse[((long)b * H + h) * N + q] = m * scale + __logf(l);
+    const float inv = 1.0f / l;
     T* orow = out + ((long)b * N + q) * H * DH + h * DH;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      f32x16 o = zero16();
-#pragma unroll
-      for (int kt = 0; kt < NT; ++kt) o = mma_imgT_acc<T, DH>(imgV, kt * 32, dt * 32, s[kt], o, lane);
-      store_tile_T<T>(orow + dt * 32, qv, o, inv, lane);
-    }
+    for (int dt = 0; dt < DT; ++dt) store_tile_T<T>(orow + dt * 32, qv, o[dt], inv, lane);
   }
 }
 
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const
     f32x16 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
-#pragma unroll
+#pragma unroll 1
     for (int kt = 0; kt < NT; ++kt) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(cons
       dk[dt] = zero16();
       dv[dt] = zero16();
     }
-#pragma unroll
+#pragma unroll 1
     for (int qt = 0; qt < NT; ++qt) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll

@@ -95,10 +95,29 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// erf-GELU (timm Mlp act_layer=nn.GELU, exact form) and its derivative.
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU (timm Mlp act_layer=nn.GELU, exact erf form) and its derivative.
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32
+// round-off level): one v_exp + one v_rcp + 6 FMAs instead of libm's branchy erff; the exponential
+// exp(-x^2/2) is shared with the Gaussian pdf that the derivative needs.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.2316418882f * ax);  // 0.3275911 / sqrt(2)
+  e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);       // exp(-x^2/2)
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float half_erfc = 0.5f * p * t * e;  // 0.5 * erfc(|x|/sqrt2)
+  cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return cdf + x * 0.39894228040143267794f * e;
 }

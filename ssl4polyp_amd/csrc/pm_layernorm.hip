@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      long lddres, float* __restrict__ dx, long lddx,
                                                      TAct* __restrict__ dx_act, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, float* __restrict__ dcolsum, int M, int D) {
+                                                     float* __restrict__ dbeta, float* __restrict__ dcolsum,
+                                                     float* __restrict__ partials, int M, int D) {
   __shared__ float red[3][4][256 + 4];  // [vector][wave][lane*4 + e] per vec slot, reused per slot
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -147,15 +148,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
     if (wave < 3 && c < nvec) {
       float* dst = wave == 0 ? dgamma : (wave == 1 ? dbeta : dcolsum);
       if (dst) {
+        f32x4 t;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = (red[wave][0][lane * 4 + e] + red[wave][1][lane * 4 + e]) +
-                          (red[wave][2][lane * 4 + e] + red[wave][3][lane * 4 + e]);
-          atomicAdd(dst + 4 * c + e, t);
+        for (int e = 0; e < 4; ++e)
+          t[e] = (red[wave][0][lane * 4 + e] + red[wave][1][lane * 4 + e]) +
+                 (red[wave][2][lane * 4 + e] + red[wave][3][lane * 4 + e]);
+        if (partials) {  // two-stage: plain store of this block's partial row, summed by ln_bwd_reduce_kernel
+          *reinterpret_cast<f32x4*>(partials + ((long)blockIdx.x * 3 + wave) * D + 4 * c) = t;
+        } else {         // no workspace: one atomic per column per block (contended when the grid is large)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(dst + 4 * c + e, t[e]);
         }
       }
     }
   }
+}
+
+// dst_v[d] += sum over blocks of partials[b][v][d], fixed order (deterministic)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partials, float* dgamma, float* dbeta,
+                                                            float* dcolsum, int nblocks, int D) {
+  // 64 columns per block, 4 row groups (one per wave) each summing every 4th partial row with 4 independent
+  // accumulators; the order of additions is fixed by (nblocks) only -> run-to-run deterministic.
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + lane;
+  const int v = blockIdx.y;
+  float* dst = v == 0 ? dgamma : (v == 1 ? dbeta : dcolsum);
+  if (!dst) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (d < D) {
+    const float* p = partials + (long)v * D + d;
+    const long stride = 3L * D;
+    int b = rg;
+    for (; b + 12 < nblocks; b += 16) {
+      s0 += p[(long)b * stride];
+      s1 += p[(long)(b + 4) * stride];
+      s2 += p[(long)(b + 8) * stride];
+      s3 += p[(long)(b + 12) * stride];
+    }
+    for (; b < nblocks; b += 4) s0 += p[(long)b * stride];
+  }
+  red[rg][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && d < D) dst[d] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 inline int ln_grid(int M) {
@@ -184,18 +219,32 @@ extern "C" int pm_layernorm_fwd(const float* x, long ldx, const float* gamma, co
 extern "C" int pm_layernorm_bwd(const void* dy, int dy_dtype, const float* x, long ldx, const float* gamma,
                                 const float* mean, const float* rstd, const float* dres, long lddres, float* dx,
                                 long lddx, void* dx_act, int act_dtype, float* dgamma, float* dbeta, float* dcolsum,
-                                int M, int D, void* stream) {
+                                int M, int D, void* workspace, size_t ws_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx) return PM_EINVAL;
   if (M <= 0 || D <= 0 || D > 1024 || (D & 3) || (ldx & 3) || (lddx & 3) || (dres && (lddres & 3))) return PM_ESHAPE;
   if (dx_act && act_dtype != dy_dtype) return PM_EINVAL;
-  const int grid = ln_grid(M);
+  int grid = (M + 3) / 4;
+  float* partials = nullptr;
+  const bool want_sums = dgamma || dbeta || dcolsum;
+  if (want_sums && workspace && ws_bytes >= (size_t)64 * 3 * D * sizeof(float)) {
+    int cap = (int)(ws_bytes / ((size_t)3 * D * sizeof(float)));
+    if (cap > 512) cap = 512;
+    if (grid > cap) grid = cap;
+    partials = reinterpret_cast<float*>(workspace);
+  } else if (grid > 256) {
+    grid = 256;  // atomics fallback: keep the number of contending blocks low
+  }
+  if (grid < 1) grid = 1;
+  hipStream_t s = pm_stream(stream);
   if (dy_dtype == PM_BF16)
-    hipLaunchKernelGGL((ln_bwd_kernel<__bf16, __bf16>), dim3(grid), dim3(256), 0, pm_stream(stream), (const __bf16*)dy,
-                       x, ldx, gamma, mean, rstd, dres, lddres, dx, lddx, (__bf16*)dx_act, dgamma, dbeta, dcolsum, M, D);
+    hipLaunchKernelGGL((ln_bwd_kernel<__bf16, __bf16>), dim3(grid), dim3(256), 0, s, (const __bf16*)dy, x, ldx, gamma, mean,
+                       rstd, dres, lddres, dx, lddx, (__bf16*)dx_act, dgamma, dbeta, dcolsum, partials, M, D);
   else if (dy_dtype == PM_F32)
-    hipLaunchKernelGGL((ln_bwd_kernel<float, float>), dim3(grid), dim3(256), 0, pm_stream(stream), (const float*)dy, x,
-                       ldx, gamma, mean, rstd, dres, lddres, dx, lddx, (float*)dx_act, dgamma, dbeta, dcolsum, M, D);
+    hipLaunchKernelGGL((ln_bwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)dy, x, ldx, gamma, mean,
+                       rstd, dres, lddres, dx, lddx, (float*)dx_act, dgamma, dbeta, dcolsum, partials, M, D);
   else
     return PM_EINVAL;
+  if (partials)
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((D + 63) / 64, 3), dim3(256), 0, s, partials, dgamma, dbeta, dcolsum, grid, D);
   return pm_check_launch();
 }

@@ -56,18 +56,30 @@ class Kernels:
                                              _ptr(mean), _ptr(rstd), M, D, self.eps, _stream()), "pm_layernorm_fwd")
 
     def layernorm_bwd(self, dy, x, gamma, mean, rstd, dres, dx, dx_act, dgamma, dbeta, dcolsum, M, D):
+        ws = self._workspace(x.device)
         _lib.check(self.lib.pm_layernorm_bwd(_ptr(dy), _lib.dtype_code(dy.dtype), _ptr(x), D, _ptr(gamma), _ptr(mean),
                                              _ptr(rstd), _ptr(dres), D, _ptr(dx), D, _ptr(dx_act), self.act,
-                                             _ptr(dgamma), _ptr(dbeta), _ptr(dcolsum), M, D, _stream()),
+                                             _ptr(dgamma), _ptr(dbeta), _ptr(dcolsum), M, D, _ptr(ws), ws.numel(), _stream()),
                    "pm_layernorm_bwd")
+
+    SPLITK_WS_BYTES = 96 << 20  # scratch for split-K wgrad slabs (16 x the largest weight of ViT-B would be 151 MB;
+    #                             pm_gemm_ws picks the largest split that fits)
+
+    def _workspace(self, device):
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.device != device:
+            ws = torch.empty(self.SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
+            self._ws = ws
+        return ws
 
     def gemm(self, A, lda, a_kmajor, B, ldb, b_kmajor, bias, C, ldc, epilogue, M, N, K, aux=None, resid=None):
         in_dtype = _lib.dtype_code(A.dtype)
         if _lib.dtype_code(B.dtype) != in_dtype:
             raise _lib.PolypMaeError("pm_gemm: operand dtypes differ")
-        _lib.check(self.lib.pm_gemm(_ptr(A), lda, int(a_kmajor), _ptr(B), ldb, int(b_kmajor), in_dtype, _ptr(bias),
-                                    _ptr(C), ldc, _lib.dtype_code(C.dtype), epilogue, _ptr(aux), _ptr(resid), M, N, K,
-                                    _stream()), "pm_gemm")
+        ws = self._workspace(A.device) if (a_kmajor and b_kmajor) else None
+        _lib.check(self.lib.pm_gemm_ws(_ptr(A), lda, int(a_kmajor), _ptr(B), ldb, int(b_kmajor), in_dtype, _ptr(bias),
+                                       _ptr(C), ldc, _lib.dtype_code(C.dtype), epilogue, _ptr(aux), _ptr(resid), M, N, K,
+                                       _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "pm_gemm")
 
     def linear_fwd(self, x, W, bias, out, M, N, K, epilogue=EPI_STORE, aux=None, resid=None):
         """out[M,N] = x[M,K] @ W[N,K]^T + bias  (nn.Linear forward)."""
