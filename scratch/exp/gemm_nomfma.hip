@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(GemmArgs a) {
         stage_glds<T, XK>(nb, X, a.ldx, m0, a.M, (t + 1) * KE, wave, lane);
         stage_glds<T, WK>(nb + TILE_BYTES, W, a.ldw, n0, a.N, (t + 1) * KE, wave, lane);
       }
-      mma_kstep<T, XK, WK>(bx, bx + TILE_BYTES, wm, wn, lane, acc);
+      asm volatile("" ::: "memory");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -376,236 +376,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_generic_kernel(GemmArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// large-tile path (bf16, X k-normal): BM x BN block tile, 8 waves, 4-stage LDS-DMA ring
-// ------------------------------------------------------------------------------------------------
-// Why: with 128x128 tiles every k-step moves 32 KiB into LDS for 2.1 MFLOP (64 FLOP/B) and has only ONE stage
-// of prefetch, so a k-step can never be shorter than the global->LDS round trip.  Here a block owns 256x256
-// (or 256x128) outputs = 128 FLOP/B, a k-step is 32 elements (64-B rows: 4 chunks, XOR-swizzled by (row>>2)&3),
-// and 4 ring slots keep 3 stages (96 KiB / CU) in flight behind a COUNTED s_waitcnt vmcnt(N) and a raw
-// s_barrier (one per k-step): the DMA of stages t+1, t+2 overlaps the MFMAs of stage t.
-// Wave layout WM x WN; per-wave tile (BM/WM) x (BN/WN) = 128x64 (256^2) or 64x64 (256x128):
-// 12 / 8 ds_read_b128 per 16 / 8 MFMAs per k-step.
-constexpr int V3_STAGES = 4;
-constexpr int V3_KE = 32;                    // bf16 elements of k per stage
-constexpr int V3_STAGE_WAVE = 64 * STAGE_ROW;  // epilogue staging per wave (64 rows x 64 f32, padded)
-
-template <int ROWS>
-__device__ __forceinline__ void v3_stage_kn(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
-                                            int wave, int lane) {
-  constexpr int NI = ROWS * 64 / 1024 / 8;  // wave-instructions per wave
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int j = wave + 8 * i;
-    const int row = 16 * j + (lane >> 2), cs = lane & 3;
-    const int c = cs ^ ((row >> 2) & 3);
-    int gr = r0 + row;
-    gr = gr < R ? gr : R - 1;
-    glds16(base + (long)gr * ld + k0 + c * 8, tile + 1024 * j);
-  }
-}
-
-template <int COLS>
-__device__ __forceinline__ void v3_stage_km(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
-                                            int wave, int lane) {
-  constexpr int RB = COLS * 2;         // bytes per k-row
-  constexpr int KPI = 1024 / RB;       // k-rows per wave-instruction (2 or 4)
-  constexpr int CPR = RB / 16;         // chunks per k-row
-  constexpr int NI = 32 * RB / 1024 / 8;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int j = wave + 8 * i;
-    const int krow = KPI * j + lane / CPR, cs = lane % CPR;
-    const int c = cs ^ ((krow & 3) << 2);
-    int gc = r0 + c * 8;
-    gc = gc < R ? gc : R - 8;
-    glds16(base + (long)(k0 + krow) * ld + gc, tile + 1024 * j);
-  }
-}
-
-__device__ __forceinline__ Frag16 v3_frag_kn(const char* tile, int rb, int kk, int lane) {
-  const int row = rb + (lane & 31);
-  const int c = 2 * kk + (lane >> 5);
-  Frag16 f;
-  f.u = *reinterpret_cast<const u32x4*>(tile + row * 64 + 16 * (c ^ ((row >> 2) & 3)));
-  return f;
-}
-
-template <int RB>
-__device__ __forceinline__ Frag16 v3_frag_km(const char* tile, int rb, int kk, int lane) {
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const int ch = (rb >> 3) + 2 * (g & 1) + (p >> 1);
-  const int sw = 16 * (ch ^ (q << 2)) + 8 * (p & 1);
-  const int kbase = kk * 16 + 8 * (g >> 1) + q;
-  using lds_s4 = __attribute__((address_space(3))) short4v;
-  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + kbase * RB + sw));
-  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(tile + (kbase + 4) * RB + sw));
-  Frag16 f;
-  f.u[0] = ((unsigned)(unsigned short)lo[0]) | (((unsigned)(unsigned short)lo[1]) << 16);
-  f.u[1] = ((unsigned)(unsigned short)lo[2]) | (((unsigned)(unsigned short)lo[3]) << 16);
-  f.u[2] = ((unsigned)(unsigned short)hi[0]) | (((unsigned)(unsigned short)hi[1]) << 16);
-  f.u[3] = ((unsigned)(unsigned short)hi[2]) | (((unsigned)(unsigned short)hi[3]) << 16);
-  return f;
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else static_assert(N == 0, "add the immediate");
-}
-
-template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT>
-__global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
-  constexpr int TM = BM_ / WM, TN = BN_ / WN;      // per-wave tile
-  constexpr int MT = TM / 32, NTL = TN / 32;       // 32x32 accumulators per wave
-  constexpr int XB = BM_ * 64, WB = BN_ * 64;      // bytes per stage per side
-  constexpr int SB = XB + WB;
-  constexpr int G = SB / 1024 / 8;                 // LDS-DMA instructions per wave per stage
-  constexpr int D = STAGES - 1;                    // stages in flight
-  static_assert(WM * WN == 8 && (XB % 8192) == 0 && (WB % 8192) == 0, "8 waves, whole wave-instructions");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = tile / a.tiles_n, tn = tile % a.tiles_n;
-  const int m0 = tm * BM_, n0 = tn * BN_;
-  const int nk = a.K / V3_KE;
-  const __bf16* X = reinterpret_cast<const __bf16*>(a.X);
-  const __bf16* W = reinterpret_cast<const __bf16*>(a.W);
-
-  f32x16 acc[NTL][MT];
-#pragma unroll
-  for (int i = 0; i < NTL; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto issue = [&](int t) {
-    char* buf = smem + (t % STAGES) * SB;
-    v3_stage_kn<BM_>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
-    if constexpr (WK) v3_stage_km<BN_>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
-    else v3_stage_kn<BN_>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
-  };
-#pragma unroll
-  for (int t = 0; t < D; ++t)
-    if (t < nk) issue(t);
-
-  for (int t = 0; t < nk; ++t) {
-    // stage t must have landed (this wave's share); later stages may stay in flight
-    const int ahead = nk - 1 - t;  // stages issued after t that exist
-    if (ahead >= D - 1) wait_vmcnt<G * (D - 1)>();
-    else if (ahead == 1) wait_vmcnt<G>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // everyone's share of stage t landed; everyone finished reading stage t-1
-    const char* bx = smem + (t % STAGES) * SB;
-    const char* bw = bx + XB;
-    // all fragment reads of the k-step first (their latency then overlaps the DMA issue below), then the DMA
-    // refill of the slot that stage t-1 occupied, then 2*MT*NTL back-to-back MFMAs
-    Frag16 fw[2][NTL], fx[2][MT];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int i = 0; i < NTL; ++i) {
-        if constexpr (WK) fw[kk][i] = v3_frag_km<BN_ * 2>(bw, wn * TN + 32 * i, kk, lane);
-        else fw[kk][i] = v3_frag_kn(bw, wn * TN + 32 * i, kk, lane);
-      }
-#pragma unroll
-      for (int j = 0; j < MT; ++j) fx[kk][j] = v3_frag_kn(bx, wm * TM + 32 * j, kk, lane);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + D < nk) issue(t + D);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < NTL; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][i].h, fx[kk][j].h, acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  }
-  const int h = lane >> 5;
-  const int epi = a.epilogue;
-  if constexpr (DIRECT) {
-    // straight from registers (lane = row m, register quad = 4 consecutive n): no LDS, no block barrier -- the
-    // stores drain while the CU's other resident block keeps the MFMA pipe busy
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const int m = m0 + wm * TM + j * 32 + (lane & 31);
-      if (m >= a.M) continue;
-#pragma unroll
-      for (int i = 0; i < NTL; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * TN + i * 32 + 8 * g + 4 * h;
-          if (n >= a.N) continue;
-          f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-          epilogue4<__bf16>(a, epi, (long)m * a.ldc + n, v);
-        }
-    }
-    return;
-  }
-  __syncthreads();  // all ring slots dead: reuse LDS for the epilogue staging
-  char* st = smem + wave * V3_STAGE_WAVE;
-#pragma unroll
-  for (int mh = 0; mh < MT / 2; ++mh) {    // 64 rows of the wave tile per pass
-#pragma unroll
-    for (int nh = 0; nh < NTL / 2; ++nh) {  // 64 columns per pass
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ml = j * 32 + (lane & 31);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x16& t16 = acc[nh * 2 + i][mh * 2 + j];
-            const f32x4 v = {t16[4 * g], t16[4 * g + 1], t16[4 * g + 2], t16[4 * g + 3]};
-            *reinterpret_cast<f32x4*>(st + ml * STAGE_ROW + (i * 32 + 8 * g + 4 * h) * 4) = v;
-          }
-      }
-      __builtin_amdgcn_wave_barrier();
-      const int mw = m0 + wm * TM + mh * 64, nw = n0 + wn * TN + nh * 64;
-#pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
-        const int ml = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-        const int m = mw + ml, n = nw + c4;
-        if (m >= a.M || n >= a.N) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(st + ml * STAGE_ROW + c4 * 4);
-        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-        epilogue4<__bf16>(a, epi, (long)m * a.ldc + n, v);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-}
-
-template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT>
-int launch_v3(GemmArgs a, int wk, hipStream_t s) {
-  a.tiles_m = (a.M + BM_ - 1) / BM_;
-  a.tiles_n = (a.N + BN_ - 1) / BN_;
-  constexpr int ring = STAGES * (BM_ + BN_) * 64;
-  constexpr int stage = DIRECT ? 0 : 8 * V3_STAGE_WAVE;
-  const size_t lds = ring > stage ? ring : stage;
-  const dim3 grid(a.tiles_m * a.tiles_n), block(512);
-  if (wk) {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT>;
-    PM_ALLOW_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, a);
-  } else {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT>;
-    PM_ALLOW_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, a);
-  }
-  return pm_check_launch();
-}
-
 template <typename T>
 int launch_generic(const GemmArgs& a, int xk, int wk, hipStream_t s) {
   const dim3 grid(a.tiles_m * a.tiles_n), block(kThreads);
@@ -627,29 +397,25 @@ int launch_glds(const GemmArgs& a, int xk, int wk, hipStream_t s) {
   const size_t lds = GLDS_LDS_BYTES;
   if (!xk && !wk) {
     auto kern = gemm_glds_kernel<T, false, false>;
-    PM_ALLOW_LDS(kern, lds);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else if (!xk && wk) {
     auto kern = gemm_glds_kernel<T, false, true>;
-    PM_ALLOW_LDS(kern, lds);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else if (xk && wk) {
     auto kern = gemm_glds_kernel<T, true, true>;
-    PM_ALLOW_LDS(kern, lds);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else {
     auto kern = gemm_glds_kernel<T, true, false>;
-    PM_ALLOW_LDS(kern, lds);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   }
   return pm_check_launch();
 }
 
-int g_force_cfg = 0;  // tuning hook (not part of the ABI): 0 auto, 1 = 128x128 kernels only, 2 = 256x128, 3 = 256x256
-
 }  // namespace
-
-extern "C" void pm_debug_gemm_config(int cfg) { g_force_cfg = cfg; }
 
 extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
                           const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux,
@@ -683,26 +449,6 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
   if (!fast) {
     a.ksteps_split = 0;
     return in_dtype == PM_BF16 ? launch_generic<__bf16>(a, a_kmajor, b_kmajor, s) : launch_generic<float>(a, a_kmajor, b_kmajor, s);
-  }
-  // large-tile ring kernel: bf16, X k-normal (forward and dgrad GEMMs), big M
-  if (in_dtype == PM_BF16 && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (g_force_cfg & 15) != 1) {
-    // Tile / pipeline choice, tuned on the ViT-B/16 shapes at M = 12608 (scratch/bench_gemm2.py; all land within
-    // ~10 % of each other -- see DESIGN.md): cfg 3 = 256x256 4-stage ring, LDS-staged epilogue; 6 = same with the
-    // direct register epilogue; 4 = 128x256 3-stage, 2 blocks/CU; 7 = 128x256 2-stage, 3 blocks/CU.
-    int cfg = g_force_cfg & 15;
-    if (cfg == 0) {
-      if (epilogue == PM_EPI_GELU) cfg = 3;
-      else if (b_kmajor) cfg = (epilogue == PM_EPI_DGELU) ? 4 : 7;
-      else cfg = (N >= 2048) ? 3 : 6;
-    }
-    switch (cfg) {
-      case 2: return launch_v3<256, 128, 4, 2, 4, 2, false>(a, b_kmajor, s);
-      case 4: return launch_v3<128, 256, 2, 4, 3, 4, true>(a, b_kmajor, s);
-      case 5: return launch_v3<256, 128, 4, 2, 3, 4, true>(a, b_kmajor, s);
-      case 6: return launch_v3<256, 256, 2, 4, 4, 2, true>(a, b_kmajor, s);
-      case 7: return launch_v3<128, 256, 2, 4, 2, 4, true>(a, b_kmajor, s);
-      default: return launch_v3<256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
-    }
   }
   const int nk = K / ke;
   a.ksteps_split = nk;

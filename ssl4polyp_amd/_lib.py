@@ -13,7 +13,7 @@ PM_F32, PM_BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ACCUM = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpolypmae.so")
+LIB_PATH = os.environ.get("POLYPMAE_LIB") or os.path.join(_HERE, "lib", "libpolypmae.so")  # override: kernel A/B builds
 
 P, I, L, F = c_void_p, c_int, c_long, c_float
 

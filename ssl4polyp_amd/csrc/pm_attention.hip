@@ -359,7 +359,7 @@ int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, hipS
   const size_t lds = 2 * NT * 32 * DH * sizeof(T);
   const float scale = 1.0f / sqrtf((float)DH);
   auto kern = attn_fwd_kernel<T, DH, NT>;
-  if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  PM_ALLOW_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(NW * 64), lds, s, (const T*)qkv, (T*)out, lse, N, H, scale);
   return pm_check_launch();
 }
@@ -373,8 +373,8 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
   const float scale = 1.0f / sqrtf((float)DH);
   auto kq = attn_bwd_q_kernel<T, DH, NT>;
   auto kkv = attn_bwd_kv_kernel<T, DH, NT>;
-  if (lds > 65536) (void)hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (lds_kv > 65536) (void)hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+  PM_ALLOW_LDS(kq, lds);
+  PM_ALLOW_LDS(kkv, lds_kv);
   hipLaunchKernelGGL(kq, dim3(B * H), dim3(NW * 64), lds, s, (const T*)qkv, (const T*)out, (const T*)dout, lse, delta,
                      (T*)dqkv, N, H, scale);
   hipLaunchKernelGGL(kkv, dim3(B * H), dim3(NW * 64), lds_kv, s, (const T*)qkv, (const T*)dout, lse,

@@ -25,6 +25,17 @@ union Frag16 {
 
 static inline hipStream_t pm_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// One-time (per kernel instantiation, per process = per GPU) opt-in to > 64 KiB of dynamic LDS.  Idempotent, so the
+// unsynchronised flag is benign; keeps the per-launch host cost to the launch itself.
+#define PM_ALLOW_LDS(kern, bytes)                                                                                  \
+  do {                                                                                                             \
+    static bool pm_lds_done_ = false;                                                                              \
+    if (!pm_lds_done_) {                                                                                           \
+      (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
+      pm_lds_done_ = true;                                                                                         \
+    }                                                                                                              \
+  } while (0)
+
 static inline int pm_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? PM_OK : PM_ELAUNCH;
