@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-stats", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step as one hipGraph (auto: on for 1 GPU, off under RCCL)")
     return ap.parse_args()
 
 
@@ -181,7 +183,14 @@ def main():
     batch = args.batch or (64 if args.workload == "cls" else 256)
     model, ddp, opt = build(args.workload, args.precision, device, world, batch)
     imgs, labels = make_batch(args.workload, batch, device, rank)
-    step = make_step(args.workload, ddp, opt, imgs, labels)
+    eager_step = make_step(args.workload, ddp, opt, imgs, labels)
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    if use_graph:
+        from ssl4polyp_amd.graph import GraphedStep
+        graphed = GraphedStep(eager_step, opt, warmup=3)  # capture failures are fatal: no silent eager fallback
+        step = graphed.replay
+    else:
+        step = eager_step
 
     for _ in range(args.warmup):
         step()
@@ -201,7 +210,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     if not (loss_val == loss_val):
         sys.exit("non-finite loss in the timed region")
 
@@ -213,7 +222,7 @@ def main():
                 "frac": round(per_gpu_tflops / peak, 4), "traffic": None,
                 "basis": f"{GFLOP_PER_IMG[args.workload]} algorithmic GFLOP/img/step x img/s/GPU (BASELINE.md §3)"}
         if not args.no_kernel_stats:
-            ks, gt, gf = kernel_stats(model, step)
+            ks, gt, gf = kernel_stats(model, eager_step)
             dom = max(ks.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])
             roof["kernel"] = {"name": f"gemm_kernel<{args.precision},{dom[0]}>", **dom[1],
                               "frac": round(dom[1]["tflops"] / peak, 4)}
@@ -226,7 +235,8 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": ("ViT-B/16 classification fine-tune" if args.workload == "cls" else
                                     "MAE pre-train ViT-B/16 mask 0.75") + f", bs={batch}/GPU, 224^2, AdamW, random init",
-                       "global_batch": batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5)},
+                       "global_batch": batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
+                       "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -153,6 +153,14 @@ int pm_cls_head_bwd(const float* dlogits, const float* x, int N, const float* ga
 int pm_adamw(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long n, float lr,
              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* hipGraph-replayable form of the same update: the hyper-parameters live in DEVICE memory, one 16-float record per
+ * param group: [0] lr [1] beta1 [2] beta2 [3] eps [4] weight_decay [5] grad_scale [6] step [7] bc1 [8] 1/sqrt(bc2).
+ * pm_adamw_tick advances step and the bias corrections of `n_groups` records; pm_adamw_dev applies one record to a
+ * flat range.  A captured step therefore replays correctly while the host changes lr between replays. */
+int pm_adamw_tick(float* hyper, int n_groups, void* stream);
+int pm_adamw_dev(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long n,
+                 const float* hyper, void* stream);
+
 /* One-pass gradient statistics over a flat f32 range: out[0] += sum(g^2), out[1] += #NaN, out[2] += #Inf
  * (the device-side counterpart of tc.py:1437-1454 _compute_grad_norm and misc.py:387-400 detect_grad_anomalies). */
 int pm_grad_stats(const float* g, long n, float* out, void* stream);

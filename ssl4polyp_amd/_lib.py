@@ -39,6 +39,8 @@ SIGNATURES = {
     "pm_cls_head_fwd": [P, I, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "pm_cls_head_bwd": [P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, I, I, I, P],
     "pm_adamw": [P, P, P, P, P, I, L, F, F, F, F, F, I, F, P],
+    "pm_adamw_tick": [P, I, P],
+    "pm_adamw_dev": [P, P, P, P, P, I, L, P, P],
     "pm_grad_stats": [P, L, P, P],
 }
 

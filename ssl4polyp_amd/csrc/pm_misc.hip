@@ -277,6 +277,47 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 
+// Device-resident hyper-parameters (hipGraph-replayable optimizer step): one 16-float record per param group
+//   [0] lr [1] beta1 [2] beta2 [3] eps [4] weight_decay [5] grad_scale [6] step [7] bc1 [8] rsqrt_bc2
+constexpr int kHyperStride = 16;
+__global__ void adamw_tick_kernel(float* __restrict__ hyper, int n_groups) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  float* h = hyper + (long)g * kHyperStride;
+  const float step = h[6] + 1.0f;
+  h[6] = step;
+  h[7] = (float)(1.0 - pow((double)h[1], (double)step));
+  h[8] = (float)(1.0 / sqrt(1.0 - pow((double)h[2], (double)step)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, T* __restrict__ shadow, long n,
+                                                        const float* __restrict__ hyper) {
+  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], gscale = hyper[5];
+  const float bc1 = hyper[7], rsqrt_bc2 = hyper[8];
+  const long nvec = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    f32x4 pp = *reinterpret_cast<const f32x4*>(p + 4 * i);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * i);
+    f32x4 mm = *reinterpret_cast<const f32x4*>(m + 4 * i);
+    f32x4 vv = *reinterpret_cast<const f32x4*>(v + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gg[e] * gscale;
+      pp[e] *= (1.0f - lr * wd);
+      mm[e] = beta1 * mm[e] + (1.0f - beta1) * gr;
+      vv[e] = beta2 * vv[e] + (1.0f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[e]) * rsqrt_bc2 + eps;
+      pp[e] -= (lr / bc1) * (mm[e] / denom);
+    }
+    *reinterpret_cast<f32x4*>(p + 4 * i) = pp;
+    *reinterpret_cast<f32x4*>(m + 4 * i) = mm;
+    *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+    if (shadow) store4<T>(shadow + 4 * i, pp);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // gradient statistics in one pass: out[0] += sum g^2, out[1] += #NaN, out[2] += #Inf
 // (replaces the per-parameter host-synchronising loops of tc.py:1437-1454 and misc.py:387-400)
@@ -442,6 +483,27 @@ extern "C" int pm_adamw(float* p, const float* g, float* m, float* v, void* shad
   return pm_check_launch();
 }
 
+
+extern "C" int pm_adamw_tick(float* hyper, int n_groups, void* stream) {
+  if (!hyper) return PM_EINVAL;
+  if (n_groups <= 0) return PM_ESHAPE;
+  hipLaunchKernelGGL(adamw_tick_kernel, dim3((n_groups + 63) / 64), dim3(64), 0, pm_stream(stream), hyper, n_groups);
+  return pm_check_launch();
+}
+
+extern "C" int pm_adamw_dev(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long n,
+                            const float* hyper, void* stream) {
+  if (!p || !g || !m || !v || !hyper) return PM_EINVAL;
+  if (n <= 0 || (n & 3)) return PM_ESHAPE;
+  const dim3 grid(cap_grid(n >> 2, 256, 4096));
+  if (!shadow || shadow_dtype == PM_BF16)
+    hipLaunchKernelGGL(adamw_dev_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), p, g, m, v, (__bf16*)shadow, n, hyper);
+  else if (shadow_dtype == PM_F32)
+    hipLaunchKernelGGL(adamw_dev_kernel<float>, grid, dim3(256), 0, pm_stream(stream), p, g, m, v, (float*)shadow, n, hyper);
+  else
+    return PM_EINVAL;
+  return pm_check_launch();
+}
 
 extern "C" int pm_grad_stats(const float* g, long n, float* out, void* stream) {
   if (!g || !out) return PM_EINVAL;

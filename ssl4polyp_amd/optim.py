@@ -87,6 +87,31 @@ class FusedAdamW(torch.optim.Optimizer):
                 segs.append((r, lo, hi))
         return segs
 
+    # -- device-resident hyper-parameters (so that a captured step can be replayed as a hipGraph) ---------------
+    HYPER_STRIDE = 16  # floats per group: lr, beta1, beta2, eps, wd, grad_scale, step, bc1, rsqrt_bc2 (pm_adamw_dev)
+
+    def _host_hyper(self):
+        rows = []
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            rows.append((float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                         float(self.grad_scale)))
+        return rows
+
+    def sync_hyper(self, force: bool = False):
+        """Push lr / betas / eps / weight_decay / grad_scale to the device records when they changed on the host.
+        Called automatically by step() outside stream capture; call it yourself between graph replays."""
+        f = self._ensure_state()
+        rows = self._host_hyper()
+        if getattr(self, "_hyper", None) is None or self._hyper.device != f.device:
+            self._hyper = torch.zeros(len(rows), self.HYPER_STRIDE, dtype=torch.float32, device=f.device)
+            for gi, group in enumerate(self.param_groups):  # resume: restore the step counter
+                self._hyper[gi, 6] = float(group.get("step", 0))
+            self._hyper_host = None
+        if force or rows != self._hyper_host:
+            self._hyper[:, :6].copy_(torch.tensor(rows, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = rows
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -96,18 +121,20 @@ class FusedAdamW(torch.optim.Optimizer):
         f = self._ensure_state()
         if self.grad_sync is not None:
             self.grad_sync.wait()
+        capturing = f.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if not capturing or getattr(self, "_hyper", None) is None:
+            self.sync_hyper()
         lib = self._rt.k.lib
-        for group in self.param_groups:
-            group["step"] = int(group.get("step", 0)) + 1
-            b1, b2 = group["betas"]
+        _lib.check(lib.pm_adamw_tick(_ptr(self._hyper), len(self.param_groups), _stream()), "pm_adamw_tick")
+        for gi, group in enumerate(self.param_groups):
+            group["step"] = int(group.get("step", 0)) + 1  # host mirror (the device record is authoritative)
+            hyper = self._hyper[gi]
             for r, lo, hi in self._segments(f, group):
                 shadow = f.S[lo:hi] if (r == "mat" and f.S is not None) else None
-                _lib.check(lib.pm_adamw(_ptr(f.P[r][lo:hi]), _ptr(f.G[r][lo:hi]), _ptr(self._M[r][lo:hi]),
-                                        _ptr(self._V[r][lo:hi]), _ptr(shadow),
-                                        _lib.dtype_code(shadow.dtype) if shadow is not None else 0, hi - lo,
-                                        float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                        float(group["weight_decay"]), group["step"], float(self.grad_scale), _stream()),
-                           "pm_adamw")
+                _lib.check(lib.pm_adamw_dev(_ptr(f.P[r][lo:hi]), _ptr(f.G[r][lo:hi]), _ptr(self._M[r][lo:hi]),
+                                            _ptr(self._V[r][lo:hi]), _ptr(shadow),
+                                            _lib.dtype_code(shadow.dtype) if shadow is not None else 0, hi - lo,
+                                            _ptr(hyper), _stream()), "pm_adamw_dev")
         return loss
 
     def grad_stats(self) -> torch.Tensor:
