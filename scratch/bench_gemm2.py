@@ -28,13 +28,13 @@ cases = [
 # correctness spot check of every config against torch on one shape each layout
 ref_nt = (x.float() @ Wqkv.float().t() + b3)
 ref_nn = (x3.float() @ Wqkv.float())
-for cfg in (1, 2, 3, 4, 5, 6, 7):
+for cfg in (3, 8, 9):
     k.lib.pm_debug_gemm_config(cfg)
     k.linear_fwd(x, Wqkv, b3, o3, M, 3 * D, D); k.linear_dgrad(x3, Wqkv, oD, M, 3 * D, D)
     e1 = ((o3.float() - ref_nt).abs().max() / ref_nt.abs().max()).item()
     e2 = ((oD.float() - ref_nn).abs().max() / ref_nn.abs().max()).item()
     print(f"cfg {cfg}: NT rel err {e1:.2e}  NN rel err {e2:.2e}")
-for cfg in (1, 3, 4, 5, 6, 7):
+for cfg in (3, 6, 8, 9):
     k.lib.pm_debug_gemm_config(cfg)
     tot_t = tot_f = 0
     line = []

@@ -457,7 +457,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT>
+template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP>
 __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
   constexpr int TM = BM_ / WM, TN = BN_ / WN;      // per-wave tile
   constexpr int MT = TM / 32, NTL = TN / 32;       // 32x32 accumulators per wave
@@ -491,22 +491,9 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
     if constexpr (WK) v3_stage_km<BN_>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
     else v3_stage_kn<BN_>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
   };
-#pragma unroll
-  for (int t = 0; t < D; ++t)
-    if (t < nk) issue(t);
-
-  for (int t = 0; t < nk; ++t) {
-    // stage t must have landed (this wave's share); later stages may stay in flight
-    const int ahead = nk - 1 - t;  // stages issued after t that exist
-    if (ahead >= D - 1) wait_vmcnt<G * (D - 1)>();
-    else if (ahead == 1) wait_vmcnt<G>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // everyone's share of stage t landed; everyone finished reading stage t-1
+  auto read_frags = [&](int t, Frag16 (&fw)[2][NTL], Frag16 (&fx)[2][MT]) {
     const char* bx = smem + (t % STAGES) * SB;
     const char* bw = bx + XB;
-    // all fragment reads of the k-step first (their latency then overlaps the DMA issue below), then the DMA
-    // refill of the slot that stage t-1 occupied, then 2*MT*NTL back-to-back MFMAs
-    Frag16 fw[2][NTL], fx[2][MT];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -517,9 +504,8 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
 #pragma unroll
       for (int j = 0; j < MT; ++j) fx[kk][j] = v3_frag_kn(bx, wm * TM + 32 * j, kk, lane);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + D < nk) issue(t + D);
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma_all = [&](const Frag16 (&fw)[2][NTL], const Frag16 (&fx)[2][MT]) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -529,6 +515,59 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
         for (int j = 0; j < MT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][i].h, fx[kk][j].h, acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+  };
+
+  if constexpr (!PP) {
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+      if (t < nk) issue(t);
+    for (int t = 0; t < nk; ++t) {
+      // stage t must have landed (this wave's share); later stages may stay in flight
+      const int ahead = nk - 1 - t;  // stages issued after t that exist
+      if (ahead >= D - 1) wait_vmcnt<G * (D - 1)>();
+      else if (ahead == 1) wait_vmcnt<G>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();  // everyone's share of stage t landed; everyone finished reading stage t-1
+      // all fragment reads of the k-step first (their latency then overlaps the DMA issue below), then the DMA
+      // refill of the slot that stage t-1 occupied, then 2*MT*NTL back-to-back MFMAs
+      Frag16 fw[2][NTL], fx[2][MT];
+      read_frags(t, fw, fx);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + D < nk) issue(t + D);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(fw, fx);
+    }
+  } else {
+    // Ping-pong: waves 0-3 and 4-7 (SIMD partners: wave w and w+4 share a SIMD) run the same two-phase loop
+    //   R_t: 12 LDS fragment reads of stage t + LDS-DMA refill      M_t: 16 back-to-back MFMAs
+    // one phase apart (waves 4-7 pass one extra barrier first), so on every SIMD one wave's MFMA phase runs
+    // beside its partner's read / DMA-issue phase instead of both stalling on LDS latency together.
+    // Ring: DP = STAGES-2 stages in flight; R_t refills the slot of stage t-2, which both halves finished reading
+    // (and waited lgkmcnt(0) on) at least two barriers ago.  Stage readiness: every wave waits for its own DMA share
+    // of stage t+1 before the barrier that opens its M_t -- for the lagging half that barrier is the one that opens
+    // the leading half's R_{t+1}.
+    constexpr int DP = STAGES - 2;
+    static_assert(DP == 2, "ping-pong ring tuned for 4 slots");
+    const int gq = wave >> 2;
+#pragma unroll
+    for (int t = 0; t < DP; ++t)
+      if (t < nk) issue(t);
+    if (nk > 1) wait_vmcnt<G>(); else wait_vmcnt<0>();
+    if (gq == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nk; ++t) {
+      __builtin_amdgcn_s_barrier();  // opens R_t
+      Frag16 fw[2][NTL], fx[2][MT];
+      read_frags(t, fw, fx);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + DP < nk) issue(t + DP);
+      if (t + 2 < nk) wait_vmcnt<G>();  // stage t+1 landed, stage t+2 may fly
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();  // opens M_t
+      mma_all(fw, fx);
+    }
+    if (gq == 0) __builtin_amdgcn_s_barrier();
   }
   const int h = lane >> 5;
   const int epi = a.epilogue;
@@ -586,7 +625,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
   }
 }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false>
 int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   a.tiles_m = (a.M + BM_ - 1) / BM_;
   a.tiles_n = (a.N + BN_ - 1) / BN_;
@@ -595,11 +634,11 @@ int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   const size_t lds = ring > stage ? ring : stage;
   const dim3 grid(a.tiles_m * a.tiles_n), block(512);
   if (wk) {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   }
@@ -691,9 +730,10 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
     // direct register epilogue; 4 = 128x256 3-stage, 2 blocks/CU; 7 = 128x256 2-stage, 3 blocks/CU.
     int cfg = g_force_cfg & 15;
     if (cfg == 0) {
-      if (epilogue == PM_EPI_GELU) cfg = 3;
-      else if (b_kmajor) cfg = (epilogue == PM_EPI_DGELU) ? 4 : 7;
-      else cfg = (N >= 2048) ? 3 : 6;
+      // 256x256 ping-pong everywhere; LDS-staged epilogue for the wide act-typed outputs (qkv, fc1+GELU: whole
+      // 128-B row segments per store), direct register epilogue for f32 residual outputs and the dgrads
+      const bool wide_act = epilogue == PM_EPI_GELU || (epilogue == PM_EPI_STORE && !b_kmajor && N >= 2048);
+      cfg = wide_act ? 8 : 9;
     }
     switch (cfg) {
       case 2: return launch_v3<256, 128, 4, 2, 4, 2, false>(a, b_kmajor, s);
@@ -701,6 +741,8 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
       case 5: return launch_v3<256, 128, 4, 2, 3, 4, true>(a, b_kmajor, s);
       case 6: return launch_v3<256, 256, 2, 4, 4, 2, true>(a, b_kmajor, s);
       case 7: return launch_v3<128, 256, 2, 4, 2, 4, true>(a, b_kmajor, s);
+      case 8: return launch_v3<256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);  // ping-pong halves
+      case 9: return launch_v3<256, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);
       default: return launch_v3<256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
     }
   }

@@ -56,7 +56,7 @@ class Kernels:
                                              _ptr(mean), _ptr(rstd), M, D, self.eps, _stream()), "pm_layernorm_fwd")
 
     def layernorm_bwd(self, dy, x, gamma, mean, rstd, dres, dx, dx_act, dgamma, dbeta, dcolsum, M, D):
-        ws = self._workspace(x.device)
+        ws = self._ln_workspace(x.device)
         _lib.check(self.lib.pm_layernorm_bwd(_ptr(dy), _lib.dtype_code(dy.dtype), _ptr(x), D, _ptr(gamma), _ptr(mean),
                                              _ptr(rstd), _ptr(dres), D, _ptr(dx), D, _ptr(dx_act), self.act,
                                              _ptr(dgamma), _ptr(dbeta), _ptr(dcolsum), M, D, _ptr(ws), ws.numel(), _stream()),
@@ -64,6 +64,22 @@ class Kernels:
 
     SPLITK_WS_BYTES = 96 << 20  # scratch for split-K wgrad slabs (16 x the largest weight of ViT-B would be 151 MB;
     #                             pm_gemm_ws picks the largest split that fits)
+
+    def _ln_workspace(self, device):
+        """Per-block partial column sums of the LayerNorm backward (separate from the split-K slabs: the wgrad GEMMs
+        run concurrently on the side stream)."""
+        ws = getattr(self, "_ws_ln", None)
+        if ws is None or ws.device != device:
+            ws = torch.empty(512 * 3 * 1024 * 4, dtype=torch.uint8, device=device)
+            self._ws_ln = ws
+        return ws
+
+    def side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            self._side = st
+        return st
 
     def _workspace(self, device):
         ws = getattr(self, "_ws", None)
@@ -213,27 +229,54 @@ class BlockStack:
             din, din_act = ws.dx[o ^ 1], ws.dx_act[o ^ 1]
             if i == g.depth - 1 and not last_bias_grad_done and tr:
                 k.colsum(dx, gr["mlp.fc2.bias"], M, D)
+            # Weight gradients run on a side stream, concurrently with the dgrad chain on the main stream: the two
+            # kernels' blocks share the CUs out of phase, so one's epilogue / partial last round hides under the
+            # other's k-loop (both read the same dY; every buffer the side stream reads stays untouched until the
+            # join below).
+            main = torch.cuda.current_stream()
+            side = k.side_stream(main.device) if tr else None
+
+            def fork():
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+
             # ---- MLP branch ----
+            if tr:
+                fork()
+                with torch.cuda.stream(side):
+                    k.linear_wgrad(dx_act, bw.h_act, gr["mlp.fc2.weight"], M, D, Hd, accumulate("mlp.fc2.weight", i))
             k.linear_dgrad(dx_act, p["mlp.fc2.weight"], ws.d_hidden, M, D, Hd, EPI_DGELU, aux=bw.h_pre)
             if tr:
-                k.linear_wgrad(dx_act, bw.h_act, gr["mlp.fc2.weight"], M, D, Hd, accumulate("mlp.fc2.weight", i))
-                k.linear_wgrad(ws.d_hidden, bw.ln2, gr["mlp.fc1.weight"], M, Hd, D, accumulate("mlp.fc1.weight", i))
-                k.colsum(ws.d_hidden, gr["mlp.fc1.bias"], M, Hd)
+                fork()
+                with torch.cuda.stream(side):
+                    k.linear_wgrad(ws.d_hidden, bw.ln2, gr["mlp.fc1.weight"], M, Hd, D, accumulate("mlp.fc1.weight", i))
+                    k.colsum(ws.d_hidden, gr["mlp.fc1.bias"], M, Hd)
             k.linear_dgrad(ws.d_hidden, p["mlp.fc1.weight"], ws.d_ln, M, Hd, D)
             k.layernorm_bwd(ws.d_ln, bw.x_mid, p["norm2.weight"], bw.mean2, bw.rstd2, dx, dmid, dmid_act,
                             gr["norm2.weight"] if tr else None, gr["norm2.bias"] if tr else None,
                             gr["attn.proj.bias"] if tr else None, M, D)
             # ---- attention branch ----
-            k.linear_dgrad(dmid_act, p["attn.proj.weight"], ws.d_attn, M, D, D)
             if tr:
-                k.linear_wgrad(dmid_act, bw.attn, gr["attn.proj.weight"], M, D, D, accumulate("attn.proj.weight", i))
+                fork()
+                with torch.cuda.stream(side):
+                    k.linear_wgrad(dmid_act, bw.attn, gr["attn.proj.weight"], M, D, D, accumulate("attn.proj.weight", i))
+            k.linear_dgrad(dmid_act, p["attn.proj.weight"], ws.d_attn, M, D, D)
             k.attention_bwd(bw.qkv, bw.attn, ws.d_attn, bw.lse, ws.delta, ws.d_qkv, B, N, g.heads, g.dh)
             if tr:
-                k.linear_wgrad(ws.d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, accumulate("attn.qkv.weight", i))
-                k.colsum(ws.d_qkv, gr["attn.qkv.bias"], M, 3 * D)
-            if not need_dx_in and not tr:
+                fork()
+                with torch.cuda.stream(side):
+                    k.linear_wgrad(ws.d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, accumulate("attn.qkv.weight", i))
+                    k.colsum(ws.d_qkv, gr["attn.qkv.bias"], M, 3 * D)
+            run_ln1 = need_dx_in or tr
+            if run_ln1:
+                k.linear_dgrad(ws.d_qkv, p["attn.qkv.weight"], ws.d_ln, M, 3 * D, D)
+            if tr:  # join: the LN1 backward below overwrites dx_act's buffer, the next block d_hidden / d_qkv
+                ev = torch.cuda.Event()
+                ev.record(side)
+                main.wait_event(ev)
+            if not run_ln1:
                 return None, None
-            k.linear_dgrad(ws.d_qkv, p["attn.qkv.weight"], ws.d_ln, M, 3 * D, D)
             below_bias = None
             if i > 0 and trainable[i - 1]:
                 below_bias = G[i - 1]["mlp.fc2.bias"]
