@@ -457,7 +457,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP>
+template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false>
 __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
   constexpr int TM = BM_ / WM, TN = BN_ / WN;      // per-wave tile
   constexpr int MT = TM / 32, NTL = TN / 32;       // 32x32 accumulators per wave
@@ -473,9 +473,17 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = tile / a.tiles_n, tn = tile % a.tiles_n;
   const int m0 = tm * BM_, n0 = tn * BN_;
-  const int nk = a.K / V3_KE;
   const __bf16* X = reinterpret_cast<const __bf16*>(a.X);
   const __bf16* W = reinterpret_cast<const __bf16*>(a.W);
+  int nk = a.K / V3_KE;
+  if (a.split_k > 1) {  // split-K: this block owns k-steps [kbeg, kend) and writes an f32 partial slab
+    const int kbeg = blockIdx.y * a.ksteps_split;
+    const int kend = (kbeg + a.ksteps_split) < nk ? (kbeg + a.ksteps_split) : nk;
+    nk = kend - kbeg;
+    X += XK ? (long)kbeg * V3_KE * a.ldx : (long)kbeg * V3_KE;
+    W += WK ? (long)kbeg * V3_KE * a.ldw : (long)kbeg * V3_KE;
+    a.C = reinterpret_cast<float*>(a.C) + (long)blockIdx.y * a.M * a.ldc;
+  }
 
   f32x16 acc[NTL][MT];
 #pragma unroll
@@ -487,7 +495,8 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
 
   auto issue = [&](int t) {
     char* buf = smem + (t % STAGES) * SB;
-    v3_stage_kn<BM_>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
+    if constexpr (XK) v3_stage_km<BM_>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
+    else v3_stage_kn<BM_>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
     if constexpr (WK) v3_stage_km<BN_>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
     else v3_stage_kn<BN_>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
   };
@@ -502,7 +511,10 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
         else fw[kk][i] = v3_frag_kn(bw, wn * TN + 32 * i, kk, lane);
       }
 #pragma unroll
-      for (int j = 0; j < MT; ++j) fx[kk][j] = v3_frag_kn(bx, wm * TM + 32 * j, kk, lane);
+      for (int j = 0; j < MT; ++j) {
+        if constexpr (XK) fx[kk][j] = v3_frag_km<BM_ * 2>(bx, wm * TM + 32 * j, kk, lane);
+        else fx[kk][j] = v3_frag_kn(bx, wm * TM + 32 * j, kk, lane);
+      }
     }
   };
   auto mma_all = [&](const Frag16 (&fw)[2][NTL], const Frag16 (&fx)[2][MT]) {
@@ -645,6 +657,18 @@ int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   return pm_check_launch();
 }
 
+// wgrad shape (both operands k-major, K = #tokens): 256x128 ping-pong ring kernel, direct epilogue, split-K slabs
+int launch_v3_wgrad(GemmArgs a, hipStream_t s) {
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.N + 127) / 128;
+  constexpr int ring = 4 * (256 + 128) * 64;
+  const dim3 grid(a.tiles_m * a.tiles_n, a.split_k), block(512);
+  auto kern = gemm_v3_kernel<256, 128, 4, 2, true, 4, 2, true, true, true>;
+  PM_ALLOW_LDS(kern, ring);
+  hipLaunchKernelGGL(kern, grid, block, ring, s, a);
+  return pm_check_launch();
+}
+
 template <typename T>
 int launch_generic(const GemmArgs& a, int xk, int wk, hipStream_t s) {
   const dim3 grid(a.tiles_m * a.tiles_n), block(kThreads);
@@ -752,6 +776,33 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
   const int tiles = a.tiles_m * a.tiles_n;
   const bool splittable = workspace && !bias && c_dtype == PM_F32 && (epilogue == PM_EPI_STORE || epilogue == PM_EPI_ACCUM) &&
                           ldc == N;
+  // large-K wgrad on the ping-pong ring kernel: 256x128 tiles, split so that tiles x splits ~ one block per CU
+  if (splittable && in_dtype == PM_BF16 && a_kmajor && b_kmajor && (K % V3_KE) == 0 && K >= 2048 && M >= 256 && N >= 128 &&
+      (g_force_cfg & 15) != 1) {
+    const int t3 = ((M + 255) / 256) * ((N + 127) / 128);
+    const int nk3 = K / V3_KE;
+    int split = 256 / t3;
+    if (split > nk3 / 16) split = nk3 / 16;
+    if (split > 16) split = 16;
+    if (split < 1) split = 1;
+    while (split > 1 && (size_t)split * M * N * sizeof(float) > ws_bytes) --split;
+    GemmArgs w = a;
+    w.ksteps_split = (nk3 + split - 1) / split;
+    w.split_k = (nk3 + w.ksteps_split - 1) / w.ksteps_split;
+    void* out = a.C;
+    if (w.split_k > 1) {
+      w.C = workspace;
+      w.epilogue = PM_EPI_STORE;
+    }
+    const int st = launch_v3_wgrad(w, s);
+    if (st || w.split_k == 1) return st;
+    const long nvec = (long)M * (N >> 2);
+    int grid = (int)((nvec + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)workspace, (float*)out, ldc, M, N,
+                       w.split_k, epilogue == PM_EPI_ACCUM ? 1 : 0);
+    return pm_check_launch();
+  }
   if (splittable && tiles < 256 && nk >= 16) {
     int split = 512 / tiles;                      // fill the 2-blocks-per-CU machine once
     if (split > nk / 8) split = nk / 8;           // >= 8 k-steps per split

@@ -159,6 +159,49 @@ def test_linear_helpers_match_autograd(prec):
     assert rel(dW, 2 * Wr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K,layout,epi", [
+    (4000, 2304, 768, "nt", "store"), (4000, 768, 3072, "nt", "resid"), (4000, 1536, 512, "nt", "gelu"),
+    (4000, 768, 2304, "nn", "store"), (4000, 3072, 768, "nn", "dgelu"), (2304, 768, 4000 + 32, "tn", "store"),
+    (768, 3072, 8192, "tn", "accum"), (520, 136, 4096, "tn", "store")])
+def test_gemm_large_tile_paths(M, N, K, layout, epi):
+    """Shapes that dispatch to the 256-wide ping-pong ring kernels (forward / dgrad / split-K wgrad), tails included."""
+    from ssl4polyp_amd._lib import EPI_ACCUM, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, EPI_STORE
+    k = _k("bf16")
+    bf = torch.bfloat16
+    A, B = rnd(M, K, seed=70, scale=0.5).to(bf), rnd(N, K, seed=71, scale=0.5).to(bf)
+    acc = A.float() @ B.float().t()
+    a_mat, lda, akm = (A, K, 0) if layout != "tn" else (A.t().contiguous(), M, 1)
+    b_mat, ldb, bkm = (B, K, 0) if layout == "nt" else (B.t().contiguous(), N, 1)
+    bias = rnd(N, seed=72) if epi in ("store", "resid", "gelu") and layout != "tn" else None
+    want = acc + (bias if bias is not None else 0)
+    tol = 3e-5 * math.sqrt(K / 32)
+    if epi == "store":
+        C = torch.full((M, N), float("nan"), device=DEV, dtype=torch.float32 if layout == "tn" else bf)
+        k.gemm(a_mat, lda, akm, b_mat, ldb, bkm, bias, C, N, EPI_STORE, M, N, K)
+        assert rel(C.float(), want) < (tol if layout == "tn" else 1e-2)
+    elif epi == "accum":
+        base = rnd(M, N, seed=73)
+        C = base.clone()
+        k.gemm(a_mat, lda, akm, b_mat, ldb, bkm, None, C, N, EPI_ACCUM, M, N, K)
+        assert rel(C, base + acc) < tol
+    elif epi == "resid":
+        resid = rnd(M, N, seed=74)
+        C = torch.empty(M, N, device=DEV)
+        k.gemm(a_mat, lda, akm, b_mat, ldb, bkm, bias, C, N, EPI_RESIDUAL, M, N, K, resid=resid)
+        assert rel(C, resid + want) < tol
+    elif epi == "gelu":
+        C, aux = torch.empty(M, N, dtype=bf, device=DEV), torch.empty(M, N, dtype=bf, device=DEV)
+        k.gemm(a_mat, lda, akm, b_mat, ldb, bkm, bias, C, N, EPI_GELU, M, N, K, aux=aux)
+        assert rel(aux.float(), want) < 1e-2 and rel(C.float(), F.gelu(aux.float())) < 1e-2
+    else:
+        pre = rnd(M, N, seed=75).to(bf)
+        C = torch.empty(M, N, dtype=bf, device=DEV)
+        k.gemm(a_mat, lda, akm, b_mat, ldb, bkm, None, C, N, EPI_DGELU, M, N, K, aux=pre)
+        p32 = pre.float().requires_grad_(True)
+        F.gelu(p32).backward(acc)
+        assert rel(C.float(), p32.grad) < 1e-2
+
+
 # ------------------------------------------------------------------------------------------------
 def _attn_ref(qkv, B, N, H, dh):
     q, k_, v = qkv.float().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
