@@ -184,3 +184,4 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._M[r][lo:lo + n].copy_(st["exp_avg"].reshape(-1))
                 self._V[r][lo:lo + n].copy_(st["exp_avg_sq"].reshape(-1))
                 group["step"] = int(float(st["step"]))
+        self._hyper = None  # rebuild the device records (incl. the step counters) at the next step()

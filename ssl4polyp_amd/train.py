@@ -1,0 +1,305 @@
+"""Training-loop counterparts of the reference's two hot loops, built on the MI355X engine.
+
+  mae/engine_pretrain.py:22-100   train_one_epoch   -> train_one_epoch_mae
+  classification/train_classification.py:4446-4650  train_epoch -> train_epoch_cls
+  mae/util/lr_sched.py:9-21 / tc.py:3943-3971       LR schedules (same formulas)
+  mae/util/misc.py:306-352 / tc.py:7036-7111        checkpoint dictionaries (same keys, torch.save format)
+
+Same step order as the reference (zero_grad -> forward -> loss -> backward -> [grad stats] -> optimizer), but
+nothing in the step reads a device value back to the host: the reference's per-step `loss.item()`,
+`torch.cuda.synchronize()`, per-parameter `isnan().any()` / `float(norm)` and the per-step loss all-reduce +
+barrier (engine_pretrain.py:55,67,74,81; tc.py:4536-4551,4631-4632) are replaced by device-side accumulators
+that are read once per `log_every` steps (one tiny all-reduce there under data parallelism).
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Callable, Dict, Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------------------------------
+# schedules
+# ---------------------------------------------------------------------------------------------------
+def mae_lr(epoch: float, lr: float, min_lr: float, warmup_epochs: float, epochs: float) -> float:
+    """lr_sched.py:11-15 -- half-cycle cosine after a linear warm-up from 0; `epoch` is fractional."""
+    if epoch < warmup_epochs:
+        return lr * epoch / warmup_epochs
+    return min_lr + (lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * (epoch - warmup_epochs) / (epochs - warmup_epochs)))
+
+
+def adjust_learning_rate(optimizer, epoch: float, args) -> float:
+    """lr_sched.py:9-21 (honours per-group `lr_scale`)."""
+    lr = mae_lr(epoch, args.lr, args.min_lr, args.warmup_epochs, args.epochs)
+    for group in optimizer.param_groups:
+        group["lr"] = lr * group["lr_scale"] if "lr_scale" in group else lr
+    return lr
+
+
+def cls_cosine_lambda(epoch: int, warmup_epochs: int, total_epochs: int) -> float:
+    """tc.py:3952-3957 -- per-EPOCH cosine factor with (epoch+1)/warmup warm-up (use with LambdaLR)."""
+    if warmup_epochs > 0 and epoch < warmup_epochs:
+        return float(epoch + 1) / float(max(1, warmup_epochs))
+    progress = (epoch - warmup_epochs) / float(max(1, total_epochs - warmup_epochs))
+    progress = min(max(progress, 0.0), 1.0)
+    return 0.5 * (1.0 + math.cos(math.pi * progress))
+
+
+# ---------------------------------------------------------------------------------------------------
+# loss of the fine-tune path (tc.py:3347-3374, 6086-6104)
+# ---------------------------------------------------------------------------------------------------
+def supervised_loss(logits: torch.Tensor, targets: torch.Tensor, pos_weight: Optional[torch.Tensor] = None,
+                    class_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if logits.ndim == 2 and logits.size(1) == 2:  # binary_bce mode
+        z = logits[:, 1] - logits[:, 0]
+        return F.binary_cross_entropy_with_logits(z, targets.to(z.dtype), pos_weight=pos_weight)
+    return F.cross_entropy(logits, targets, weight=class_weights)
+
+
+# ---------------------------------------------------------------------------------------------------
+# epoch loops
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class EpochStats:
+    steps: int = 0
+    samples: int = 0
+    loss: float = float("nan")          # mean over the epoch (all ranks)
+    grad_norm: float = float("nan")     # last logged global gradient norm
+    grad_nan: int = 0
+    grad_inf: int = 0
+    seconds: float = 0.0
+    lr: float = 0.0
+    history: List[Dict[str, float]] = field(default_factory=list)
+
+    @property
+    def samples_per_sec(self) -> float:
+        return self.samples / self.seconds if self.seconds > 0 else 0.0
+
+
+def _world() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _flush(stats: EpochStats, acc: torch.Tensor, gstats: Optional[torch.Tensor], step: int, lr: float, printer):
+    """One host read-back (+ one tiny all-reduce) per log interval: acc = [sum(loss), n_steps]."""
+    buf = torch.cat([acc, gstats if gstats is not None else acc.new_zeros(3)])
+    if _world() > 1:
+        dist.all_reduce(buf)
+    vals = buf.tolist()
+    mean_loss = vals[0] / max(vals[1], 1.0)
+    if not math.isfinite(mean_loss):
+        raise FloatingPointError(f"Loss is {mean_loss}, stopping training")  # engine_pretrain.py:59-62
+    rec = {"step": step, "loss": mean_loss, "lr": lr}
+    if gstats is not None:
+        w = _world()  # every rank holds the SUM of the per-rank gradients: |mean grad| = sqrt(sum_sq / w) / w after the reduce
+        rec.update(grad_norm=math.sqrt(max(vals[2], 0.0) / w) / w, grad_nan=int(vals[3]), grad_inf=int(vals[4]))
+        stats.grad_norm, stats.grad_nan, stats.grad_inf = rec["grad_norm"], stats.grad_nan + rec["grad_nan"], \
+            stats.grad_inf + rec["grad_inf"]
+    stats.history.append(rec)
+    if printer is not None:
+        printer(rec)
+    return vals[0], vals[1]
+
+
+def train_one_epoch_mae(model, data_loader: Iterable, optimizer, device, epoch: int, args, log_every: int = 20,
+                        printer: Optional[Callable] = print, grad_stats: bool = True) -> EpochStats:
+    """engine_pretrain.py:22-100.  `model(samples, mask_ratio=...) -> (loss, pred, mask)`; `args` needs lr, min_lr,
+    warmup_epochs, epochs, accum_iter, mask_ratio.  `model` may be a parallel.DataParallel wrapper."""
+    model.train(True)
+    accum = max(int(getattr(args, "accum_iter", 1)), 1)
+    optimizer.zero_grad(set_to_none=True)
+    n_iter = len(data_loader)
+    stats = EpochStats()
+    acc = torch.zeros(2, dtype=torch.float32, device=device)   # [sum(loss), count] since the last flush
+    total, count = 0.0, 0.0
+    gs = None
+    lr = 0.0
+    t0 = time.perf_counter()
+    no_sync = getattr(model, "no_sync", None)
+    for it, batch in enumerate(data_loader):
+        samples = batch[0] if isinstance(batch, (tuple, list)) else batch
+        if it % accum == 0:
+            lr = adjust_learning_rate(optimizer, it / n_iter + epoch, args)  # per-iteration schedule
+        samples = samples.to(device, non_blocking=True)
+        last_micro = (it + 1) % accum == 0
+        if no_sync is not None and not last_micro:
+            with no_sync():
+                loss, _, _ = model(samples, mask_ratio=args.mask_ratio)
+                (loss / accum).backward()
+        else:
+            loss, _, _ = model(samples, mask_ratio=args.mask_ratio)
+            (loss / accum).backward()
+        acc[0] += loss.detach()
+        acc[1] += 1.0
+        if last_micro:
+            if grad_stats and hasattr(optimizer, "grad_stats") and (it // accum + 1) % log_every == 0:
+                gs = optimizer.grad_stats()
+            optimizer.step()
+            optimizer.zero_grad(set_to_none=True)
+        stats.steps += 1
+        stats.samples += samples.shape[0] * _world()
+        if (it + 1) % (log_every * accum) == 0 or it + 1 == n_iter:
+            s, c = _flush(stats, acc, gs, it + 1, lr, printer)
+            total, count = total + s, count + c
+            acc.zero_()
+            gs = None
+    torch.cuda.synchronize(device) if torch.device(device).type == "cuda" else None
+    stats.seconds = time.perf_counter() - t0
+    stats.loss = total / max(count, 1.0)
+    stats.lr = lr
+    return stats
+
+
+def train_epoch_cls(model, train_loader: Iterable, optimizer, device, pos_weight: Optional[torch.Tensor] = None,
+                    class_weights: Optional[torch.Tensor] = None, max_batches: Optional[int] = None, log_every: int = 20,
+                    printer: Optional[Callable] = print, grad_stats: bool = True) -> EpochStats:
+    """tc.py:4446-4650 hot loop: zero_grad -> model(data) -> BCE/CE -> backward -> grad norm -> optimizer.step().
+    Batches are (data, target) or (data, target, meta) as produced by the reference's pack_collate."""
+    model.train(True)
+    stats = EpochStats()
+    acc = torch.zeros(2, dtype=torch.float32, device=device)
+    total, count = 0.0, 0.0
+    gs = None
+    t0 = time.perf_counter()
+    n = 0
+    for it, batch in enumerate(train_loader):
+        if max_batches is not None and it >= max_batches:
+            break
+        data, target = batch[0], batch[1]
+        data = data.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        optimizer.zero_grad(set_to_none=True)
+        output = model(data)
+        loss = supervised_loss(output, target, pos_weight, class_weights)
+        loss.backward()
+        if grad_stats and hasattr(optimizer, "grad_stats") and (it + 1) % log_every == 0:
+            gs = optimizer.grad_stats()
+        optimizer.step()
+        acc[0] += loss.detach()
+        acc[1] += 1.0
+        stats.steps += 1
+        stats.samples += data.shape[0] * _world()
+        n = it + 1
+        if n % log_every == 0:
+            s, c = _flush(stats, acc, gs, n, optimizer.param_groups[0]["lr"], printer)
+            total, count = total + s, count + c
+            acc.zero_()
+            gs = None
+    if n % log_every != 0 and n > 0:
+        s, c = _flush(stats, acc, gs, n, optimizer.param_groups[0]["lr"], printer)
+        total, count = total + s, count + c
+    torch.cuda.synchronize(device) if torch.device(device).type == "cuda" else None
+    stats.seconds = time.perf_counter() - t0
+    stats.loss = total / max(count, 1.0)
+    stats.lr = optimizer.param_groups[0]["lr"]
+    return stats
+
+
+@torch.no_grad()
+def evaluate_cls(model, loader: Iterable, device, max_batches: Optional[int] = None):
+    """tc.py:4652-4812 forward part: logits and targets gathered on the host (metrics stay in the reference's code)."""
+    model.eval()
+    logits, targets = [], []
+    for it, batch in enumerate(loader):
+        if max_batches is not None and it >= max_batches:
+            break
+        logits.append(model(batch[0].to(device, non_blocking=True)).float().cpu())
+        targets.append(batch[1].cpu())
+    return torch.cat(logits), torch.cat(targets)
+
+
+# ---------------------------------------------------------------------------------------------------
+# checkpoints
+# ---------------------------------------------------------------------------------------------------
+def _unwrap(model):
+    return getattr(model, "module", model)
+
+
+def _is_main() -> bool:
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+def save_mae_checkpoint(output_dir, epoch: int, model, optimizer, args, scaler_state: Optional[dict] = None) -> Path:
+    """misc.py:306-335: <out>/checkpoint-<epoch>.pth = {model, optimizer, epoch, scaler, args} + last.pth symlink.
+    (`scaler` is kept for format compatibility: bf16 needs no loss scaling.)"""
+    out = Path(output_dir)
+    path = out / f"checkpoint-{epoch}.pth"
+    if _is_main():
+        out.mkdir(parents=True, exist_ok=True)
+        to_save = {"model": {k: v.detach().cpu() for k, v in _unwrap(model).state_dict().items()},
+                   "optimizer": optimizer.state_dict(), "epoch": epoch, "scaler": scaler_state or {}, "args": args}
+        torch.save(to_save, path)
+        last = out / "last.pth"
+        try:
+            if last.is_symlink() or last.exists():
+                last.unlink()
+            last.symlink_to(path.name)
+        except OSError:
+            pass
+    return path
+
+
+def load_mae_checkpoint(path, model, optimizer=None, args=None) -> int:
+    """misc.py:338-352: restores model (+ optimizer and start epoch).  Returns the next epoch to run."""
+    ckpt = torch.load(str(path), map_location="cpu", weights_only=False)
+    _unwrap(model).load_state_dict(ckpt["model"])
+    start = 0
+    if optimizer is not None and "optimizer" in ckpt and "epoch" in ckpt:
+        optimizer.load_state_dict(ckpt["optimizer"])
+        start = int(ckpt["epoch"]) + 1
+        if args is not None:
+            args.start_epoch = start
+    return start
+
+
+def save_cls_checkpoint(path, epoch: int, model, optimizer, scheduler=None, loss: Optional[float] = None,
+                        extra: Optional[dict] = None) -> Path:
+    """tc.py:7036-7067 payload keys (model_state_dict / optimizer_state_dict / scaler_state_dict / scheduler_state_dict
+    / epoch / loss + RNG states); `extra` carries the reference's val_* / monitor_* / threshold fields unchanged."""
+    import random
+
+    import numpy as np
+    path = Path(path)
+    if _is_main():
+        path.parent.mkdir(parents=True, exist_ok=True)
+        payload = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in _unwrap(model).state_dict().items()},
+                   "optimizer_state_dict": optimizer.state_dict(), "scaler_state_dict": {},
+                   "scheduler_state_dict": scheduler.state_dict() if scheduler is not None else None, "loss": loss,
+                   "python_random_state": random.getstate(), "numpy_random_state": np.random.get_state(),
+                   "torch_rng_state": torch.get_rng_state()}
+        if torch.cuda.is_available():
+            payload["cuda_rng_state_all"] = torch.cuda.get_rng_state_all()
+        payload.update(extra or {})
+        torch.save(payload, path)
+    return path
+
+
+# ---------------------------------------------------------------------------------------------------
+# synthetic loader (the reference's PIL / torchvision pipeline is out of scope: SURVEY §8-f rank 2)
+# ---------------------------------------------------------------------------------------------------
+class SyntheticLoader:
+    """Post-transform Hyperkvasir/SUN-shaped batches resident on the device: imgs ~ N(0,1) [B,3,S,S], labels ~ Bern(.5)."""
+
+    def __init__(self, batch_size: int, n_batches: int, device, img_size: int = 224, seed: int = 1234, fresh: bool = False):
+        self.batch_size, self.n, self.device, self.fresh = batch_size, n_batches, device, fresh
+        g = torch.Generator(device=device).manual_seed(seed)
+        self.gen = g
+        self.imgs = torch.randn(batch_size, 3, img_size, img_size, generator=g, device=device)
+        self.labels = (torch.rand(batch_size, generator=g, device=device) < 0.5).long()
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for _ in range(self.n):
+            if self.fresh:
+                self.imgs.normal_(generator=self.gen)
+                self.labels = (torch.rand(self.batch_size, generator=self.gen, device=self.device) < 0.5).long()
+            yield self.imgs, self.labels
