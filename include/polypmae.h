@@ -89,6 +89,10 @@ int pm_attention_bwd(const void* qkv, const void* out, const void* dout, const f
 
 /* Column sums of a [M,N] act matrix into f32 [N] (+=) -- bias gradients of qkv / fc1 / decoder Linears. */
 int pm_colsum(const void* x, long ldx, int dtype, float* out, int M, int N, void* stream);
+/* Deterministic form: per-split partial rows go to `workspace` (>= 128*N*4 bytes) and are summed in a fixed order;
+ * without a workspace the splits are combined with float atomics (order-dependent last bits). */
+int pm_colsum_ws(const void* x, long ldx, int dtype, float* out, int M, int N, void* workspace, size_t ws_bytes,
+                 void* stream);
 
 /* Patch extraction (the im2col of timm PatchEmbed's Conv2d k=s=p), optionally only the kept patches
  * of MAE random masking (models_mae.py:141-142 applied BEFORE the projection, which is the same

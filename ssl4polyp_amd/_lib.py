@@ -26,6 +26,7 @@ SIGNATURES = {
     "pm_attention_fwd": [P, P, P, I, I, I, I, I, P],
     "pm_attention_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "pm_colsum": [P, L, I, P, I, I, P],
+    "pm_colsum_ws": [P, L, I, P, I, I, P, ctypes.c_size_t, P],
     "pm_patch_im2col": [P, P, P, I, I, I, I, I, I, P],
     "pm_assemble_tokens": [P, P, P, P, P, I, I, I, P],
     "pm_assemble_tokens_bwd": [P, P, P, I, P, P, I, I, I, P],

@@ -9,8 +9,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // column sums: out[n] += sum_m x[m][n]   (bias gradients)
 // ---------------------------------------------------------------------------------------------
+// `partials` != NULL: each (column strip, row split) block stores its partial row [blockIdx.y][N]; colsum_reduce_kernel
+// then sums the splits in a fixed order (deterministic).  NULL: one float atomic per column per block.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ldx, float* __restrict__ out, int M, int N) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ldx, float* __restrict__ out,
+                                                     float* __restrict__ partials, int M, int N) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 256 + lane * 4;
@@ -23,7 +26,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
   __syncthreads();
   const int t = threadIdx.x;
   const int nn = blockIdx.x * 256 + t;
-  if (nn < N) atomicAdd(out + nn, (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+  if (nn < N) {
+    const float s = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (partials) partials[(long)blockIdx.y * N + nn] = s;
+    else atomicAdd(out + nn, s);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out,
+                                                            int splits, int N) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < splits; r += 4) {
+    s0 += partials[(long)r * N + n];
+    s1 += partials[(long)(r + 1) * N + n];
+    s2 += partials[(long)(r + 2) * N + n];
+    s3 += partials[(long)(r + 3) * N + n];
+  }
+  for (; r < splits; ++r) s0 += partials[(long)r * N + n];
+  out[n] += (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -366,17 +389,26 @@ inline int cap_grid(long work_items, int per_block, int cap) {
 
 }  // namespace
 
-extern "C" int pm_colsum(const void* x, long ldx, int dtype, float* out, int M, int N, void* stream) {
+extern "C" int pm_colsum_ws(const void* x, long ldx, int dtype, float* out, int M, int N, void* workspace, size_t ws_bytes,
+                            void* stream) {
   if (!x || !out) return PM_EINVAL;
   if (M <= 0 || N <= 0 || (N & 3) || (ldx & 3)) return PM_ESHAPE;
-  const dim3 grid((N + 255) / 256, cap_grid(M, 64, 128));
+  const int splits = cap_grid(M, 64, 128);
+  const dim3 grid((N + 255) / 256, splits);
+  float* partials = (workspace && ws_bytes >= (size_t)splits * N * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
+  hipStream_t s = pm_stream(stream);
   if (dtype == PM_BF16)
-    hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), (const __bf16*)x, ldx, out, M, N);
+    hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, ldx, out, partials, M, N);
   else if (dtype == PM_F32)
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, pm_stream(stream), (const float*)x, ldx, out, M, N);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, out, partials, M, N);
   else
     return PM_EINVAL;
+  if (partials) hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, partials, out, splits, N);
   return pm_check_launch();
+}
+
+extern "C" int pm_colsum(const void* x, long ldx, int dtype, float* out, int M, int N, void* stream) {
+  return pm_colsum_ws(x, ldx, dtype, out, M, N, nullptr, 0, stream);
 }
 
 extern "C" int pm_patch_im2col(const float* imgs, const int* ids_keep, void* cols, int out_dtype, int B, int C, int img,

@@ -110,7 +110,15 @@ class Kernels:
         self.gemm(dy, N_out, 1, x, K_in, 1, None, dW, K_in, EPI_ACCUM if accumulate else EPI_STORE, N_out, K_in, M)
 
     def colsum(self, x, out, M, N):
-        _lib.check(self.lib.pm_colsum(_ptr(x), N, _lib.dtype_code(x.dtype), _ptr(out), M, N, _stream()), "pm_colsum")
+        # partial rows: one scratch per stream (main / wgrad side stream) so concurrent column sums never share it
+        on_side = getattr(self, "_side", None) is not None and torch.cuda.current_stream() == self._side
+        key = "_ws_cs_side" if on_side else "_ws_cs_main"
+        ws = getattr(self, key, None)
+        if ws is None or ws.device != x.device:
+            ws = torch.empty(128 * 4096 * 4, dtype=torch.uint8, device=x.device)
+            setattr(self, key, ws)
+        _lib.check(self.lib.pm_colsum_ws(_ptr(x), N, _lib.dtype_code(x.dtype), _ptr(out), M, N, _ptr(ws), ws.numel(),
+                                         _stream()), "pm_colsum")
 
     def attention_fwd(self, qkv, out, lse, B, N, H, dh):
         _lib.check(self.lib.pm_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, N, H, dh, self.act, _stream()),
