@@ -393,10 +393,11 @@ constexpr int V3_STAGE_WAVE = 64 * STAGE_ROW;  // epilogue staging per wave (64 
 template <int ROWS>
 __device__ __forceinline__ void v3_stage_kn(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
                                             int wave, int lane) {
-  constexpr int NI = ROWS * 64 / 1024 / 8;  // wave-instructions per wave
+  constexpr int TI = ROWS * 64 / 1024;  // wave-instructions for the tile, dealt round-robin to the 8 waves
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
+  for (int i = 0; i < (TI + 7) / 8; ++i) {
     const int j = wave + 8 * i;
+    if (j >= TI) break;  // (192-row tiles: waves 4-7 issue one instruction less)
     const int row = 16 * j + (lane >> 2), cs = lane & 3;
     const int c = cs ^ ((row >> 2) & 3);
     int gr = r0 + row;
@@ -463,9 +464,10 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
   constexpr int MT = TM / 32, NTL = TN / 32;       // 32x32 accumulators per wave
   constexpr int XB = BM_ * 64, WB = BN_ * 64;      // bytes per stage per side
   constexpr int SB = XB + WB;
-  constexpr int G = SB / 1024 / 8;                 // LDS-DMA instructions per wave per stage
+  constexpr int G = (SB / 1024 + 7) / 8;           // LDS-DMA instructions per wave per stage (max over waves)
   constexpr int D = STAGES - 1;                    // stages in flight
-  static_assert(WM * WN == 8 && (XB % 8192) == 0 && (WB % 8192) == 0, "8 waves, whole wave-instructions");
+  static_assert(WM * WN == 8 && (WB % 8192) == 0 && ((XB % 8192) == 0 || (PP && !XK && XB == 12288 && DIRECT)),
+                "8 waves; whole wave-instructions per wave, except the 192-row k-normal X tile of the ping-pong kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -564,7 +566,17 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
 #pragma unroll
     for (int t = 0; t < DP; ++t)
       if (t < nk) issue(t);
-    if (nk > 1) wait_vmcnt<G>(); else wait_vmcnt<0>();
+    // DMA instructions per stage of THIS wave: G for whole tiles; 192-row X tiles deal 12 instructions to 8 waves,
+    // so waves 4-7 (= the lagging half) issue G - 1
+    constexpr bool UNEVEN = (XB % 8192) != 0;
+    auto wait_one_stage_in_flight = [&]() {
+      if constexpr (UNEVEN) {
+        if (gq == 0) wait_vmcnt<G>(); else wait_vmcnt<G - 1>();
+      } else {
+        wait_vmcnt<G>();
+      }
+    };
+    if (nk > 1) wait_one_stage_in_flight(); else wait_vmcnt<0>();
     if (gq == 1) __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nk; ++t) {
       __builtin_amdgcn_s_barrier();  // opens R_t
@@ -572,7 +584,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
       read_frags(t, fw, fx);
       __builtin_amdgcn_sched_barrier(0);
       if (t + DP < nk) issue(t + DP);
-      if (t + 2 < nk) wait_vmcnt<G>();  // stage t+1 landed, stage t+2 may fly
+      if (t + 2 < nk) wait_one_stage_in_flight();  // stage t+1 landed, stage t+2 may fly
       else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -758,6 +770,11 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
       // 128-B row segments per store), direct register epilogue for f32 residual outputs and the dgrads
       const bool wide_act = epilogue == PM_EPI_GELU || (epilogue == PM_EPI_STORE && !b_kmajor && N >= 2048);
       cfg = wide_act ? 8 : 9;
+      if (cfg == 9) {  // whole tiles per CU round: 192-row tiles when they need fewer (rounds x rows)
+        const long nt = (N + 255) / 256;
+        const long c256 = (((M + 255) / 256 * nt + 255) / 256) * 256, c192 = (((M + 191) / 192 * nt + 255) / 256) * 192;
+        if (c192 < c256) cfg = 10;
+      }
     }
     switch (cfg) {
       case 2: return launch_v3<256, 128, 4, 2, 4, 2, false>(a, b_kmajor, s);
@@ -767,6 +784,7 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
       case 7: return launch_v3<128, 256, 2, 4, 2, 4, true>(a, b_kmajor, s);
       case 8: return launch_v3<256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);  // ping-pong halves
       case 9: return launch_v3<256, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);
+      case 10: return launch_v3<192, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);  // 192-row tiles: finer M granularity
       default: return launch_v3<256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
     }
   }
