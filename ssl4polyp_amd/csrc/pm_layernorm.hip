@@ -165,11 +165,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
 }
 
 // dst_v[d] += sum over blocks of partials[b][v][d], fixed order (deterministic)
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partials, float* dgamma, float* dbeta,
-                                                            float* dcolsum, int nblocks, int D) {
-  // 64 columns per block, 4 row groups (one per wave) each summing every 4th partial row with 4 independent
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ partials, float* dgamma, float* dbeta,
+                                                             float* dcolsum, int nblocks, int D) {
+  // 64 columns per block, 16 row groups (one per wave) each summing every 16th partial row with 4 independent
   // accumulators; the order of additions is fixed by (nblocks) only -> run-to-run deterministic.
-  __shared__ float red[4][64];
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int d = blockIdx.x * 64 + lane;
   const int v = blockIdx.y;
@@ -180,17 +180,22 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     const float* p = partials + (long)v * D + d;
     const long stride = 3L * D;
     int b = rg;
-    for (; b + 12 < nblocks; b += 16) {
+    for (; b + 48 < nblocks; b += 64) {
       s0 += p[(long)b * stride];
-      s1 += p[(long)(b + 4) * stride];
-      s2 += p[(long)(b + 8) * stride];
-      s3 += p[(long)(b + 12) * stride];
+      s1 += p[(long)(b + 16) * stride];
+      s2 += p[(long)(b + 32) * stride];
+      s3 += p[(long)(b + 48) * stride];
     }
-    for (; b < nblocks; b += 4) s0 += p[(long)b * stride];
+    for (; b < nblocks; b += 16) s0 += p[(long)b * stride];
   }
   red[rg][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (rg == 0 && d < D) dst[d] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (rg == 0 && d < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][lane];
+    dst[d] += t;
+  }
 }
 
 inline int ln_grid(int M) {
@@ -228,7 +233,7 @@ extern "C" int pm_layernorm_bwd(const void* dy, int dy_dtype, const float* x, lo
   const bool want_sums = dgamma || dbeta || dcolsum;
   if (want_sums && workspace && ws_bytes >= (size_t)64 * 3 * D * sizeof(float)) {
     int cap = (int)(ws_bytes / ((size_t)3 * D * sizeof(float)));
-    if (cap > 512) cap = 512;
+    if (cap > 1024) cap = 1024;
     if (grid > cap) grid = cap;
     partials = reinterpret_cast<float*>(workspace);
   } else if (grid > 256) {
@@ -245,6 +250,6 @@ extern "C" int pm_layernorm_bwd(const void* dy, int dy_dtype, const float* x, lo
   else
     return PM_EINVAL;
   if (partials)
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((D + 63) / 64, 3), dim3(256), 0, s, partials, dgamma, dbeta, dcolsum, grid, D);
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((D + 63) / 64, 3), dim3(1024), 0, s, partials, dgamma, dbeta, dcolsum, grid, D);
   return pm_check_launch();
 }

@@ -70,7 +70,7 @@ class Kernels:
         run concurrently on the side stream)."""
         ws = getattr(self, "_ws_ln", None)
         if ws is None or ws.device != device:
-            ws = torch.empty(512 * 3 * 1024 * 4, dtype=torch.uint8, device=device)
+            ws = torch.empty(1024 * 3 * 1024 * 4, dtype=torch.uint8, device=device)
             self._ws_ln = ws
         return ws
 
