@@ -183,7 +183,9 @@ class StackWorkspace:
             self.d_qkv = e(M, 3 * D)
             self.delta = e(B * g.heads * N, dt=f32)
             self.dx = [e(M, D, dt=f32), e(M, D, dt=f32)]
-            self.dx_act = [e(M, D), e(M, D)]
+            # three act-typed copies of the residual gradient: the wgrad GEMMs read them on the side stream while the
+            # main stream already produces the next one (see BlockStack.backward)
+            self.dx_act = [e(M, D), e(M, D), e(M, D)]
 
     def block(self, i: int) -> BlockWorkspace:
         return self.blocks[i if self.training else i % len(self.blocks)]
@@ -233,8 +235,13 @@ class BlockStack:
             xin = x_in if i == 0 else ws.block(i - 1).x_out
             need_dx_in = need_input_grad or i > lowest
             o = i & 1
-            dmid, dmid_act = ws.dx[o], ws.dx_act[o]
-            din, din_act = ws.dx[o ^ 1], ws.dx_act[o ^ 1]
+            dmid, din = ws.dx[o], ws.dx[o ^ 1]  # f32 residual gradients: main stream only, ping-pong (in-place add is fine)
+            # act copies rotate through three buffers: the incoming one is read by wgrad(fc2) on the side stream until
+            # the join below, so LN2-backward must write a DIFFERENT buffer; after the join the incoming one is free
+            # again and would be a valid target, but LN1-backward takes the third so that wgrad(proj) (reading dmid_act)
+            # can never alias it either.
+            pin = next((j for j in range(3) if dx_act is ws.dx_act[j]), 2)
+            dmid_act, din_act = ws.dx_act[(pin + 1) % 3], ws.dx_act[(pin + 2) % 3]
             if i == g.depth - 1 and not last_bias_grad_done and tr:
                 k.colsum(dx, gr["mlp.fc2.bias"], M, D)
             # Weight gradients run on a side stream, concurrently with the dgrad chain on the main stream: the two
