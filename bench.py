@@ -175,11 +175,19 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # rehearsal hook (one-GPU box): BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo, so the N>1 code path
+    # (rendezvous, broadcast, bucketed overlap, max-over-ranks timing) can be exercised without N GPUs
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     batch = args.batch or (64 if args.workload == "cls" else 256)
     model, ddp, opt = build(args.workload, args.precision, device, world, batch)
     imgs, labels = make_batch(args.workload, batch, device, rank)
