@@ -458,7 +458,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false>
+template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false, bool DM = false>
 __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
   constexpr int TM = BM_ / WM, TN = BN_ / WN;      // per-wave tile
   constexpr int MT = TM / 32, NTL = TN / 32;       // 32x32 accumulators per wave
@@ -560,8 +560,10 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
     // (and waited lgkmcnt(0) on) at least two barriers ago.  Stage readiness: every wave waits for its own DMA share
     // of stage t+1 before the barrier that opens its M_t -- for the lagging half that barrier is the one that opens
     // the leading half's R_{t+1}.
-    constexpr int DP = STAGES - 2;
-    static_assert(DP == 2, "ping-pong ring tuned for 4 slots");
+    // DM = false: R_t refills slot (t+2)%4 (2 stages in flight).  DM = true: the refill of slot (t+3)%4 is issued in
+    // M_t between the MFMAs (3 stages in flight; the read phase -- the critical one -- gets shorter).
+    constexpr int DP = DM ? STAGES - 1 : STAGES - 2;
+    static_assert(STAGES == 4, "ping-pong ring tuned for 4 slots");
     const int gq = wave >> 2;
 #pragma unroll
     for (int t = 0; t < DP; ++t)
@@ -576,20 +578,49 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
         wait_vmcnt<G>();
       }
     };
-    if (nk > 1) wait_one_stage_in_flight(); else wait_vmcnt<0>();
+    auto wait_two_stages_in_flight = [&]() {
+      if constexpr (UNEVEN) {
+        if (gq == 0) wait_vmcnt<2 * G>(); else wait_vmcnt<2 * G - 2>();
+      } else {
+        wait_vmcnt<2 * G>();
+      }
+    };
+    if (DM && nk > 2) wait_two_stages_in_flight();
+    else if (nk > 1) wait_one_stage_in_flight();
+    else wait_vmcnt<0>();
     if (gq == 1) __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nk; ++t) {
       __builtin_amdgcn_s_barrier();  // opens R_t
       Frag16 fw[2][NTL], fx[2][MT];
       read_frags(t, fw, fx);
       __builtin_amdgcn_sched_barrier(0);
-      if (t + DP < nk) issue(t + DP);
+      if constexpr (!DM) {
+        if (t + DP < nk) issue(t + DP);
+      }
       if (t + 2 < nk) wait_one_stage_in_flight();  // stage t+1 landed, stage t+2 may fly
       else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();  // opens M_t
-      mma_all(fw, fx);
+      if constexpr (DM) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+          for (int j = 0; j < MT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[0][i].h, fx[0][j].h, acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + DP < nk) issue(t + DP);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+          for (int j = 0; j < MT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[1][i].h, fx[1][j].h, acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        mma_all(fw, fx);
+      }
     }
     if (gq == 0) __builtin_amdgcn_s_barrier();
   }
@@ -649,7 +680,7 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
   }
 }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, bool DM = false>
 int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   a.tiles_m = (a.M + BM_ - 1) / BM_;
   a.tiles_n = (a.N + BN_ - 1) / BN_;
@@ -658,11 +689,11 @@ int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   const size_t lds = ring > stage ? ring : stage;
   const dim3 grid(a.tiles_m * a.tiles_n), block(512);
   if (wk) {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP, false, DM>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP, false, DM>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   }
@@ -785,6 +816,9 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
       case 8: return launch_v3<256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);  // ping-pong halves
       case 9: return launch_v3<256, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);
       case 10: return launch_v3<192, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);  // 192-row tiles: finer M granularity
+      case 11: return launch_v3<256, 256, 2, 4, 4, 2, false, true, true>(a, b_kmajor, s);  // DMA refill inside the MFMA phase
+      case 12: return launch_v3<256, 256, 2, 4, 4, 2, true, true, true>(a, b_kmajor, s);
+      case 13: return launch_v3<192, 256, 2, 4, 4, 2, true, true, true>(a, b_kmajor, s);
       default: return launch_v3<256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
     }
   }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-template <typename TDy, typename TAct>
+template <typename TDy, typename TAct, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
                                                      float* __restrict__ dbeta, float* __restrict__ dcolsum,
                                                      float* __restrict__ partials, int M, int D) {
   __shared__ float red[3][4][256 + 4];  // [vector][wave][lane*4 + e] per vec slot, reused per slot
+  constexpr int kMaxVec = NV;  // f32x4 slots per lane for this D (shadows the file-scope bound): D <= 256 * NV
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nvec = D >> 2;
@@ -88,48 +89,79 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDy* __restrict__ dy,
     acc_c[i] = z;
   }
   const float invD = 1.0f / (float)D;
-  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
-    const float mu = mean[row];
-    const float rs = rstd[row];
-    const float* xr = x + row * ldx;
-    const TDy* dyr = dy + row * (long)D;
-    f32x4 xh[kMaxVec], dv[kMaxVec];
-    float s1 = 0.f, s2 = 0.f;
+  // Two rows per wave per iteration: their loads and the two shuffle-reduction chains are independent, which is the
+  // instruction-level parallelism this latency-bound loop was missing (one wave otherwise serialises
+  // load -> 2 x 6 shuffles -> store per row).
+  const long stride = (long)gridDim.x * 4;
+  for (long row0 = (long)blockIdx.x * 4 + wave; row0 < M; row0 += 2 * stride) {
+    long rows[2] = {row0, row0 + stride};
+    const bool valid[2] = {true, rows[1] < M};
+    if (!valid[1]) rows[1] = row0;  // harmless duplicate loads; contributions and stores are suppressed below
+    float mu[2], rs[2], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    f32x4 xh[2][kMaxVec], dv[2][kMaxVec], dr[2][kMaxVec];
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvec) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-        dv[i] = load4<TDy>(dyr + 4 * c);
+    for (int u = 0; u < 2; ++u) {
+      mu[u] = mean[rows[u]];
+      rs[u] = rstd[rows[u]];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[i][e] = (xv[e] - mu) * rs;
-          const float gg = dv[i][e] * g[i][e];
-          s1 += gg;
-          s2 += gg * xh[i][e];
-          acc_g[i][e] += dv[i][e] * xh[i][e];
-          acc_b[i][e] += dv[i][e];
+      for (int i = 0; i < kMaxVec; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+          xh[u][i] = *reinterpret_cast<const f32x4*>(x + rows[u] * ldx + 4 * c);
+          dv[u][i] = load4<TDy>(dy + rows[u] * (long)D + 4 * c);
+          if (dres) dr[u][i] = *reinterpret_cast<const f32x4*>(dres + rows[u] * lddres + 4 * c);
         }
       }
     }
-    const float c1 = wave_sum(s1) * invD;
-    const float c2 = wave_sum(s2) * invD;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvec) {
-        f32x4 o;
+    for (int u = 0; u < 2; ++u) {
+      const float live = valid[u] ? 1.0f : 0.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (dv[i][e] * g[i][e] - c1 - xh[i][e] * c2);
-        if (dres) {
-          const f32x4 r = *reinterpret_cast<const f32x4*>(dres + row * lddres + 4 * c);
+      for (int i = 0; i < kMaxVec; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += r[e];
+          for (int e = 0; e < 4; ++e) {
+            xh[u][i][e] = (xh[u][i][e] - mu[u]) * rs[u];
+            const float gg = dv[u][i][e] * g[i][e];
+            s1[u] += gg;
+            s2[u] += gg * xh[u][i][e];
+            acc_g[i][e] += live * dv[u][i][e] * xh[u][i][e];
+            acc_b[i][e] += live * dv[u][i][e];
+          }
         }
-        *reinterpret_cast<f32x4*>(dx + row * lddx + 4 * c) = o;
-        if (dx_act) store4<TAct>(dx_act + row * (long)D + 4 * c, o);
+      }
+    }
+    float c1[2], c2[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc_c[i][e] += o[e];
+    for (int u = 0; u < 2; ++u) {
+      c1[u] = s1[u];
+      c2[u] = s2[u];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {  // the four reductions interleaved
+      c1[0] += __shfl_xor(c1[0], o, 64);
+      c1[1] += __shfl_xor(c1[1], o, 64);
+      c2[0] += __shfl_xor(c2[0], o, 64);
+      c2[1] += __shfl_xor(c2[1], o, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!valid[u]) continue;
+      const float k1 = c1[u] * invD, k2 = c2[u] * invD;
+#pragma unroll
+      for (int i = 0; i < kMaxVec; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rs[u] * (dv[u][i][e] * g[i][e] - k1 - xh[u][i][e] * k2);
+          if (dres) o += dr[u][i];
+          *reinterpret_cast<f32x4*>(dx + rows[u] * lddx + 4 * c) = o;
+          if (dx_act) store4<TAct>(dx_act + rows[u] * (long)D + 4 * c, o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc_c[i][e] += o[e];
+        }
       }
     }
   }
@@ -241,14 +273,18 @@ extern "C" int pm_layernorm_bwd(const void* dy, int dy_dtype, const float* x, lo
   }
   if (grid < 1) grid = 1;
   hipStream_t s = pm_stream(stream);
-  if (dy_dtype == PM_BF16)
-    hipLaunchKernelGGL((ln_bwd_kernel<__bf16, __bf16>), dim3(grid), dim3(256), 0, s, (const __bf16*)dy, x, ldx, gamma, mean,
-                       rstd, dres, lddres, dx, lddx, (__bf16*)dx_act, dgamma, dbeta, dcolsum, partials, M, D);
-  else if (dy_dtype == PM_F32)
-    hipLaunchKernelGGL((ln_bwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)dy, x, ldx, gamma, mean,
-                       rstd, dres, lddres, dx, lddx, (float*)dx_act, dgamma, dbeta, dcolsum, partials, M, D);
-  else
+  const int nv = (D + 255) / 256;  // f32x4 slots per lane: 3 for D = 768, 2 for 512
+#define PM_LN_BWD(TD, NV)                                                                                               \
+  hipLaunchKernelGGL((ln_bwd_kernel<TD, TD, NV>), dim3(grid), dim3(256), 0, s, (const TD*)dy, x, ldx, gamma, mean, rstd, \
+                     dres, lddres, dx, lddx, (TD*)dx_act, dgamma, dbeta, dcolsum, partials, M, D)
+  if (dy_dtype == PM_BF16) {
+    if (nv == 1) PM_LN_BWD(__bf16, 1); else if (nv == 2) PM_LN_BWD(__bf16, 2); else if (nv == 3) PM_LN_BWD(__bf16, 3); else PM_LN_BWD(__bf16, 4);
+  } else if (dy_dtype == PM_F32) {
+    if (nv == 1) PM_LN_BWD(float, 1); else if (nv == 2) PM_LN_BWD(float, 2); else if (nv == 3) PM_LN_BWD(float, 3); else PM_LN_BWD(float, 4);
+  } else {
     return PM_EINVAL;
+  }
+#undef PM_LN_BWD
   if (partials)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((D + 63) / 64, 3), dim3(1024), 0, s, partials, dgamma, dbeta, dcolsum, grid, D);
   return pm_check_launch();
