@@ -100,6 +100,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// sum of p[b * stride] for b = first, first + step, ... < n, in that fixed order (deterministic), with U loads in
+// flight at a time (the second-stage reductions are latency-bound otherwise)
+template <int U>
+__device__ __forceinline__ float strided_sum(const float* __restrict__ p, long stride, int first, int step, int n) {
+  float s = 0.f;
+  int b = first;
+  for (; b + (U - 1) * step < n; b += U * step) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = p[(long)(b + u * step) * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) s += v[u];
+  }
+  for (; b < n; b += step) s += p[(long)b * stride];
+  return s;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

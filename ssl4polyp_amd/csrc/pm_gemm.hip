@@ -390,13 +390,13 @@ constexpr int V3_STAGES = 4;
 constexpr int V3_KE = 32;                    // bf16 elements of k per stage
 constexpr int V3_STAGE_WAVE = 64 * STAGE_ROW;  // epilogue staging per wave (64 rows x 64 f32, padded)
 
-template <int ROWS>
+template <int ROWS, int NW = 8>
 __device__ __forceinline__ void v3_stage_kn(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
                                             int wave, int lane) {
-  constexpr int TI = ROWS * 64 / 1024;  // wave-instructions for the tile, dealt round-robin to the 8 waves
+  constexpr int TI = ROWS * 64 / 1024;  // wave-instructions for the tile, dealt round-robin to the NW waves
 #pragma unroll
-  for (int i = 0; i < (TI + 7) / 8; ++i) {
-    const int j = wave + 8 * i;
+  for (int i = 0; i < (TI + NW - 1) / NW; ++i) {
+    const int j = wave + NW * i;
     if (j >= TI) break;  // (192-row tiles: waves 4-7 issue one instruction less)
     const int row = 16 * j + (lane >> 2), cs = lane & 3;
     const int c = cs ^ ((row >> 2) & 3);
@@ -406,16 +406,16 @@ __device__ __forceinline__ void v3_stage_kn(char* tile, const __bf16* __restrict
   }
 }
 
-template <int COLS>
+template <int COLS, int NW = 8>
 __device__ __forceinline__ void v3_stage_km(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
                                             int wave, int lane) {
   constexpr int RB = COLS * 2;         // bytes per k-row
   constexpr int KPI = 1024 / RB;       // k-rows per wave-instruction (2 or 4)
   constexpr int CPR = RB / 16;         // chunks per k-row
-  constexpr int NI = 32 * RB / 1024 / 8;
+  constexpr int NI = 32 * RB / 1024 / NW;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int j = wave + 8 * i;
+    const int j = wave + NW * i;
     const int krow = KPI * j + lane / CPR, cs = lane % CPR;
     const int c = cs ^ ((krow & 3) << 2);
     int gc = r0 + c * 8;
@@ -458,16 +458,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false, bool DM = false>
-__global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
+template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false, bool DM = false,
+          int NW = 8>
+__global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
   constexpr int TM = BM_ / WM, TN = BN_ / WN;      // per-wave tile
   constexpr int MT = TM / 32, NTL = TN / 32;       // 32x32 accumulators per wave
   constexpr int XB = BM_ * 64, WB = BN_ * 64;      // bytes per stage per side
   constexpr int SB = XB + WB;
-  constexpr int G = (SB / 1024 + 7) / 8;           // LDS-DMA instructions per wave per stage (max over waves)
+  constexpr int G = (SB / 1024 + NW - 1) / NW;     // LDS-DMA instructions per wave per stage (max over waves)
   constexpr int D = STAGES - 1;                    // stages in flight
-  static_assert(WM * WN == 8 && (WB % 8192) == 0 && ((XB % 8192) == 0 || (PP && !XK && XB == 12288 && DIRECT)),
-                "8 waves; whole wave-instructions per wave, except the 192-row k-normal X tile of the ping-pong kernel");
+  static_assert(WM * WN == NW && (NW == 8 || (NW == 4 && !PP)) && (WB % (1024 * NW)) == 0 &&
+                    ((XB % (1024 * NW)) == 0 || (PP && !XK && XB == 12288 && DIRECT)),
+                "NW waves (ping-pong: 8); whole wave-instructions per wave, except the 192-row k-normal X tile of the "
+                "ping-pong kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -497,10 +500,10 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
 
   auto issue = [&](int t) {
     char* buf = smem + (t % STAGES) * SB;
-    if constexpr (XK) v3_stage_km<BM_>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
-    else v3_stage_kn<BM_>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
-    if constexpr (WK) v3_stage_km<BN_>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
-    else v3_stage_kn<BN_>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
+    if constexpr (XK) v3_stage_km<BM_, NW>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
+    else v3_stage_kn<BM_, NW>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
+    if constexpr (WK) v3_stage_km<BN_, NW>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
+    else v3_stage_kn<BN_, NW>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
   };
   auto read_frags = [&](int t, Frag16 (&fw)[2][NTL], Frag16 (&fx)[2][MT]) {
     const char* bx = smem + (t % STAGES) * SB;
@@ -680,20 +683,20 @@ __global__ __launch_bounds__(512, MINW) void gemm_v3_kernel(GemmArgs a) {
   }
 }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, bool DM = false>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, bool DM = false, int NW = 8>
 int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   a.tiles_m = (a.M + BM_ - 1) / BM_;
   a.tiles_n = (a.N + BN_ - 1) / BN_;
   constexpr int ring = STAGES * (BM_ + BN_) * 64;
-  constexpr int stage = DIRECT ? 0 : 8 * V3_STAGE_WAVE;
+  constexpr int stage = DIRECT ? 0 : NW * V3_STAGE_WAVE;
   const size_t lds = ring > stage ? ring : stage;
-  const dim3 grid(a.tiles_m * a.tiles_n), block(512);
+  const dim3 grid(a.tiles_m * a.tiles_n), block(NW * 64);
   if (wk) {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP, false, DM>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP, false, DM, NW>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP, false, DM>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP, false, DM, NW>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   }
@@ -791,11 +794,11 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
     return in_dtype == PM_BF16 ? launch_generic<__bf16>(a, a_kmajor, b_kmajor, s) : launch_generic<float>(a, a_kmajor, b_kmajor, s);
   }
   // large-tile ring kernel: bf16, X k-normal (forward and dgrad GEMMs), big M
-  if (in_dtype == PM_BF16 && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (g_force_cfg & 15) != 1) {
+  if (in_dtype == PM_BF16 && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (g_force_cfg & 63) != 1) {
     // Tile / pipeline choice, tuned on the ViT-B/16 shapes at M = 12608 (scratch/bench_gemm2.py; all land within
     // ~10 % of each other -- see DESIGN.md): cfg 3 = 256x256 4-stage ring, LDS-staged epilogue; 6 = same with the
     // direct register epilogue; 4 = 128x256 3-stage, 2 blocks/CU; 7 = 128x256 2-stage, 3 blocks/CU.
-    int cfg = g_force_cfg & 15;
+    int cfg = g_force_cfg & 63;
     if (cfg == 0) {
       // 256x256 ping-pong everywhere; LDS-staged epilogue for the wide act-typed outputs (qkv, fc1+GELU: whole
       // 128-B row segments per store), direct register epilogue for f32 residual outputs and the dgrads
@@ -819,6 +822,13 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
       case 11: return launch_v3<256, 256, 2, 4, 4, 2, false, true, true>(a, b_kmajor, s);  // DMA refill inside the MFMA phase
       case 12: return launch_v3<256, 256, 2, 4, 4, 2, true, true, true>(a, b_kmajor, s);
       case 13: return launch_v3<192, 256, 2, 4, 4, 2, true, true, true>(a, b_kmajor, s);
+      // 4-wave blocks, two (or three) independent blocks per CU: one block's epilogue / prologue runs under the other's k-loop
+      case 16: return launch_v3<128, 256, 2, 2, 3, 2, true, false, false, 4>(a, b_kmajor, s);
+      case 17: return launch_v3<128, 256, 2, 2, 3, 2, false, false, false, 4>(a, b_kmajor, s);
+      case 18: return launch_v3<256, 128, 2, 2, 3, 2, true, false, false, 4>(a, b_kmajor, s);
+      case 19: return launch_v3<256, 128, 2, 2, 3, 2, false, false, false, 4>(a, b_kmajor, s);
+      case 20: return launch_v3<128, 128, 2, 2, 3, 3, true, false, false, 4>(a, b_kmajor, s);
+      case 21: return launch_v3<128, 128, 2, 2, 4, 2, true, false, false, 4>(a, b_kmajor, s);
       default: return launch_v3<256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
     }
   }
@@ -830,7 +840,7 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
                           ldc == N;
   // large-K wgrad on the ping-pong ring kernel: 256x128 tiles, split so that tiles x splits ~ one block per CU
   if (splittable && in_dtype == PM_BF16 && a_kmajor && b_kmajor && (K % V3_KE) == 0 && K >= 2048 && M >= 256 && N >= 128 &&
-      (g_force_cfg & 15) != 1) {
+      (g_force_cfg & 63) != 1) {
     const int t3 = ((M + 255) / 256) * ((N + 127) / 128);
     const int nk3 = K / V3_KE;
     int split = 256 / t3;

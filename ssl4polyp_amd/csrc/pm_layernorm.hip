@@ -207,20 +207,9 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
   const int v = blockIdx.y;
   float* dst = v == 0 ? dgamma : (v == 1 ? dbeta : dcolsum);
   if (!dst) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (d < D) {
-    const float* p = partials + (long)v * D + d;
-    const long stride = 3L * D;
-    int b = rg;
-    for (; b + 48 < nblocks; b += 64) {
-      s0 += p[(long)b * stride];
-      s1 += p[(long)(b + 16) * stride];
-      s2 += p[(long)(b + 32) * stride];
-      s3 += p[(long)(b + 48) * stride];
-    }
-    for (; b < nblocks; b += 16) s0 += p[(long)b * stride];
-  }
-  red[rg][lane] = (s0 + s1) + (s2 + s3);
+  float s0 = 0.f;
+  if (d < D) s0 = strided_sum<16>(partials + (long)v * D + d, 3L * D, rg, 16, nblocks);
+  red[rg][lane] = s0;
   __syncthreads();
   if (rg == 0 && d < D) {
     float t = 0.f;

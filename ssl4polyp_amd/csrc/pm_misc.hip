@@ -33,24 +33,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out,
-                                                            int splits, int N) {
-  // 64 columns per block; the 4 waves each sum every 4th split (fixed order), then one LDS combine
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out,
+                                                             int splits, int N) {
+  // 64 columns per block; the 16 waves each sum every 16th split (fixed order, 8 loads in flight), then one LDS combine
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f;
-  if (n < N) {
-    int r = rg;
-    for (; r + 4 < splits; r += 8) {
-      s0 += partials[(long)r * N + n];
-      s1 += partials[(long)(r + 4) * N + n];
-    }
-    for (; r < splits; r += 4) s0 += partials[(long)r * N + n];
-  }
-  red[rg][lane] = s0 + s1;
+  red[rg][lane] = n < N ? strided_sum<8>(partials + n, N, rg, 16, splits) : 0.f;
   __syncthreads();
-  if (rg == 0 && n < N) out[n] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (rg == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][lane];
+    out[n] += t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -407,7 +403,7 @@ extern "C" int pm_colsum_ws(const void* x, long ldx, int dtype, float* out, int 
     hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, out, partials, M, N);
   else
     return PM_EINVAL;
-  if (partials) hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 63) / 64), dim3(256), 0, s, partials, out, splits, N);
+  if (partials) hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, partials, out, splits, N);
   return pm_check_launch();
 }
 

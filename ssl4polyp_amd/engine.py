@@ -177,15 +177,17 @@ class StackWorkspace:
         self.training = training
         if training:
             e = lambda *s, dt=act_dtype: torch.empty(*s, dtype=dt, device=dev)
-            self.d_hidden = e(M, Hd)
+            # The weight-gradient GEMMs of block i run on a side stream and may still be in flight while the main
+            # stream is one block further down (see BlockStack.backward): what they read is double-buffered by block
+            # parity (d_hidden, d_qkv) or rotates through five buffers (act copies of the residual gradient: block i
+            # uses slots p, p+1, p+2, block i-1 slots p+2, p+3, p+4).
+            self.d_hidden = [e(M, Hd), e(M, Hd)]
+            self.d_qkv = [e(M, 3 * D), e(M, 3 * D)]
             self.d_ln = e(M, D)
             self.d_attn = e(M, D)
-            self.d_qkv = e(M, 3 * D)
             self.delta = e(B * g.heads * N, dt=f32)
             self.dx = [e(M, D, dt=f32), e(M, D, dt=f32)]
-            # three act-typed copies of the residual gradient: the wgrad GEMMs read them on the side stream while the
-            # main stream already produces the next one (see BlockStack.backward)
-            self.dx_act = [e(M, D), e(M, D), e(M, D)]
+            self.dx_act = [e(M, D) for _ in range(5)]
 
     def block(self, i: int) -> BlockWorkspace:
         return self.blocks[i if self.training else i % len(self.blocks)]
@@ -228,27 +230,35 @@ class BlockStack:
         k, g = self.k, self.g
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
         lowest = min([i for i, t in enumerate(trainable) if t], default=g.depth)
+        main = torch.cuda.current_stream()
+        pending: Dict[int, torch.cuda.Event] = {}  # block -> side-stream event after its last weight-gradient kernel
+
+        def join(down_to: int):
+            for j in sorted((j for j in pending if j >= down_to), reverse=True):
+                main.wait_event(pending.pop(j))
+
         for i in reversed(range(g.depth)):
             if i < lowest and not need_input_grad:
+                join(0)
                 return None, None
             bw, p, gr, tr = ws.block(i), W[i], G[i], trainable[i]
             xin = x_in if i == 0 else ws.block(i - 1).x_out
             need_dx_in = need_input_grad or i > lowest
             o = i & 1
             dmid, din = ws.dx[o], ws.dx[o ^ 1]  # f32 residual gradients: main stream only, ping-pong (in-place add is fine)
-            # act copies rotate through three buffers: the incoming one is read by wgrad(fc2) on the side stream until
-            # the join below, so LN2-backward must write a DIFFERENT buffer; after the join the incoming one is free
-            # again and would be a valid target, but LN1-backward takes the third so that wgrad(proj) (reading dmid_act)
-            # can never alias it either.
-            pin = next((j for j in range(3) if dx_act is ws.dx_act[j]), 2)
-            dmid_act, din_act = ws.dx_act[(pin + 1) % 3], ws.dx_act[(pin + 2) % 3]
+            d_hidden, d_qkv = ws.d_hidden[o], ws.d_qkv[o]
+            # act copies rotate through five buffers, two steps per block: wgrad(fc2) / wgrad(proj) of this block read
+            # the incoming one / dmid_act on the side stream, possibly until the main stream has finished block i-1,
+            # which writes the next two slots.
+            pin = next((j for j in range(5) if dx_act is ws.dx_act[j]), 4)
+            dmid_act, din_act = ws.dx_act[(pin + 1) % 5], ws.dx_act[(pin + 2) % 5]
+            join(i + 2)  # block i overwrites what the side stream read for block i+2
             if i == g.depth - 1 and not last_bias_grad_done and tr:
                 k.colsum(dx, gr["mlp.fc2.bias"], M, D)
             # Weight gradients run on a side stream, concurrently with the dgrad chain on the main stream: the two
             # kernels' blocks share the CUs out of phase, so one's epilogue / partial last round hides under the
             # other's k-loop (both read the same dY; every buffer the side stream reads stays untouched until the
             # join below).
-            main = torch.cuda.current_stream()
             side = k.side_stream(main.device) if tr else None
 
             def fork():
@@ -261,13 +271,13 @@ class BlockStack:
                 fork()
                 with torch.cuda.stream(side):
                     k.linear_wgrad(dx_act, bw.h_act, gr["mlp.fc2.weight"], M, D, Hd, accumulate("mlp.fc2.weight", i))
-            k.linear_dgrad(dx_act, p["mlp.fc2.weight"], ws.d_hidden, M, D, Hd, EPI_DGELU, aux=bw.h_pre)
+            k.linear_dgrad(dx_act, p["mlp.fc2.weight"], d_hidden, M, D, Hd, EPI_DGELU, aux=bw.h_pre)
             if tr:
                 fork()
                 with torch.cuda.stream(side):
-                    k.linear_wgrad(ws.d_hidden, bw.ln2, gr["mlp.fc1.weight"], M, Hd, D, accumulate("mlp.fc1.weight", i))
-                    k.colsum(ws.d_hidden, gr["mlp.fc1.bias"], M, Hd)
-            k.linear_dgrad(ws.d_hidden, p["mlp.fc1.weight"], ws.d_ln, M, Hd, D)
+                    k.linear_wgrad(d_hidden, bw.ln2, gr["mlp.fc1.weight"], M, Hd, D, accumulate("mlp.fc1.weight", i))
+                    k.colsum(d_hidden, gr["mlp.fc1.bias"], M, Hd)
+            k.linear_dgrad(d_hidden, p["mlp.fc1.weight"], ws.d_ln, M, Hd, D)
             k.layernorm_bwd(ws.d_ln, bw.x_mid, p["norm2.weight"], bw.mean2, bw.rstd2, dx, dmid, dmid_act,
                             gr["norm2.weight"] if tr else None, gr["norm2.bias"] if tr else None,
                             gr["attn.proj.bias"] if tr else None, M, D)
@@ -277,20 +287,23 @@ class BlockStack:
                 with torch.cuda.stream(side):
                     k.linear_wgrad(dmid_act, bw.attn, gr["attn.proj.weight"], M, D, D, accumulate("attn.proj.weight", i))
             k.linear_dgrad(dmid_act, p["attn.proj.weight"], ws.d_attn, M, D, D)
-            k.attention_bwd(bw.qkv, bw.attn, ws.d_attn, bw.lse, ws.delta, ws.d_qkv, B, N, g.heads, g.dh)
+            k.attention_bwd(bw.qkv, bw.attn, ws.d_attn, bw.lse, ws.delta, d_qkv, B, N, g.heads, g.dh)
             if tr:
                 fork()
                 with torch.cuda.stream(side):
-                    k.linear_wgrad(ws.d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, accumulate("attn.qkv.weight", i))
-                    k.colsum(ws.d_qkv, gr["attn.qkv.bias"], M, 3 * D)
+                    k.linear_wgrad(d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, accumulate("attn.qkv.weight", i))
+                    k.colsum(d_qkv, gr["attn.qkv.bias"], M, 3 * D)
+                    # no join here: the main stream runs on into block i-1 and waits for this event only before
+                    # block i-2.  The block's matrix gradients are final in side-stream order.
+                    pending[i] = torch.cuda.Event()
+                    pending[i].record(side)
+                    if on_block_done is not None:
+                        on_block_done(i)
             run_ln1 = need_dx_in or tr
             if run_ln1:
-                k.linear_dgrad(ws.d_qkv, p["attn.qkv.weight"], ws.d_ln, M, 3 * D, D)
-            if tr:  # join: the LN1 backward below overwrites dx_act's buffer, the next block d_hidden / d_qkv
-                ev = torch.cuda.Event()
-                ev.record(side)
-                main.wait_event(ev)
+                k.linear_dgrad(d_qkv, p["attn.qkv.weight"], ws.d_ln, M, 3 * D, D)
             if not run_ln1:
+                join(0)
                 return None, None
             below_bias = None
             if i > 0 and trainable[i - 1]:
@@ -300,6 +313,7 @@ class BlockStack:
             k.layernorm_bwd(ws.d_ln, xin, p["norm1.weight"], bw.mean1, bw.rstd1, dmid, din, din_act,
                             gr["norm1.weight"] if tr else None, gr["norm1.bias"] if tr else None, below_bias, M, D)
             dx, dx_act = din, din_act
-            if on_block_done is not None:
+            if on_block_done is not None and not tr:
                 on_block_done(i)
+        join(0)
         return dx, dx_act
