@@ -95,6 +95,19 @@ template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v) {
   }
 }
 
+// 8 consecutive bf16 as one 16-B access (a wave store instruction costs the CU's store path ~64 cycles whatever
+// its width: 16 B per lane halves the epilogue's store time against 8 B per lane)
+__device__ __forceinline__ void load8_bf16(const __bf16* p, f32x4& lo, f32x4& hi) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+  lo = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  hi = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+}
+__device__ __forceinline__ void store8_bf16(__bf16* p, f32x4 lo, f32x4 hi) {
+  const bf16x8 o = {(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3],
+                    (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

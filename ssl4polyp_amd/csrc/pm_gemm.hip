@@ -28,6 +28,7 @@
 //   gemm_generic_kernel (any K % chunk == 0): register-staged, fully predicated loads (tiny / odd shapes).
 // Roofline: MFMA-bound; algorithmic FLOPs 2*M*N*K.
 #include "pm_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -53,7 +54,23 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int split_k;       // >1: blockIdx.y = split, C = f32 slabs [split][M][ldc]
   int ksteps_split;  // k-steps per split
+#ifdef PM_GEMM_STAMP
+  unsigned long long* stamps;  // diagnostic build only: per-wave cycle sums of the k-loop segments
+#endif
 };
+
+// Diagnostic build (-DPM_GEMM_STAMP, scratch/stamp_gemm.py): s_memtime stamps around the segments of the ping-pong
+// k-loop.  The shipped library never executes a stamp.
+#ifdef PM_GEMM_STAMP
+#define PM_STAMP(i)                               \
+  do {                                            \
+    __builtin_amdgcn_sched_barrier(0);            \
+    stamp_t[i] = __builtin_readcyclecounter();    \
+    __builtin_amdgcn_sched_barrier(0);            \
+  } while (0)
+#else
+#define PM_STAMP(i)
+#endif
 
 // ---- global -> register staging (generic kernel) ---------------------------------------------------
 template <typename T, bool KMAJOR>
@@ -211,6 +228,90 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int epi, long off, 
     else
       store4<__bf16>(reinterpret_cast<__bf16*>(a.C) + off, v);
   }
+}
+
+// The same epilogues on NV vectors at once: every load the epilogue needs (residual / saved pre-activation / C) is
+// issued before the first store, so the loads overlap instead of forming one load -> store latency chain per vector
+// (stamped on the 256x256 tile: 25.6k cycles per wave for 32 dependent chains).  off[] must be valid addresses (the
+// caller clamps rows / columns beyond M / N); ok[] gates the stores.
+template <int NV>
+__device__ __forceinline__ void epilogue_batch(const GemmArgs& a, int epi, const long (&off)[NV], const bool (&ok)[NV],
+                                               f32x4 (&v)[NV]) {
+  if (epi == PM_EPI_RESIDUAL || epi == PM_EPI_ACCUM) {
+    const float* src = epi == PM_EPI_RESIDUAL ? a.resid : reinterpret_cast<const float*>(a.C);
+    f32x4 r[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) r[e] = *reinterpret_cast<const f32x4*>(src + off[e]);
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+      if (ok[e]) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.C) + off[e]) = r[e] + v[e];
+    return;
+  }
+  if (epi == PM_EPI_DGELU) {
+    f32x4 pre[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) pre[e] = load4<__bf16>(reinterpret_cast<const __bf16*>(a.aux) + off[e]);
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[e][k] *= gelu_erf_grad(pre[e][k]);
+  } else if (epi == PM_EPI_GELU) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      if (ok[e]) store4<__bf16>(reinterpret_cast<__bf16*>(a.aux) + off[e], v[e]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[e][k] = gelu_erf(to_f32<__bf16>(from_f32<__bf16>(v[e][k])));  // what backward will see
+    }
+  }
+  if (a.c_dtype == PM_F32) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+      if (ok[e]) store4<float>(reinterpret_cast<float*>(a.C) + off[e], v[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < NV; ++e)
+      if (ok[e]) store4<__bf16>(reinterpret_cast<__bf16*>(a.C) + off[e], v[e]);
+  }
+}
+
+// 8 consecutive n per vector, act-typed (bf16) C, epilogues STORE / GELU / DGELU: 16-B accesses.
+template <int NV>
+__device__ __forceinline__ void epilogue_batch8(const GemmArgs& a, int epi, const long (&off)[NV], const bool (&ok)[NV],
+                                                f32x4 (&lo)[NV], f32x4 (&hi)[NV]) {
+  if (epi == PM_EPI_DGELU) {
+    f32x4 plo[NV], phi[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) load8_bf16(reinterpret_cast<const __bf16*>(a.aux) + off[u], plo[u], phi[u]);
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        lo[u][k] *= gelu_erf_grad(plo[u][k]);
+        hi[u][k] *= gelu_erf_grad(phi[u][k]);
+      }
+  } else if (epi == PM_EPI_GELU) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      if (ok[u]) store8_bf16(reinterpret_cast<__bf16*>(a.aux) + off[u], lo[u], hi[u]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // gelu of the value backward will see (the bf16-rounded pre-activation)
+        lo[u][k] = gelu_erf(to_f32<__bf16>(from_f32<__bf16>(lo[u][k])));
+        hi[u][k] = gelu_erf(to_f32<__bf16>(from_f32<__bf16>(hi[u][k])));
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NV; ++u)
+    if (ok[u]) store8_bf16(reinterpret_cast<__bf16*>(a.C) + off[u], lo[u], hi[u]);
+}
+
+// exchange between lane l and lane l+32: afterwards the low half-wave holds (x of lane l, x of lane l+32) in (x, y)
+// and the high half-wave holds (y of lane l-32, y of its own) -- v_permlane32_swap
+__device__ __forceinline__ void swap_halves(float& x, float& y) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -390,6 +491,16 @@ constexpr int V3_STAGES = 4;
 constexpr int V3_KE = 32;                    // bf16 elements of k per stage
 constexpr int V3_STAGE_WAVE = 64 * STAGE_ROW;  // epilogue staging per wave (64 rows x 64 f32, padded)
 
+// One 1-KiB LDS-DMA piece j of a k-normal tile (16 rows x 64 B; the lane's SOURCE chunk is the inverse swizzle of its slot).
+__device__ __forceinline__ void v3_piece_kn(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
+                                            int j, int lane) {
+  const int row = 16 * j + (lane >> 2), cs = lane & 3;
+  const int c = cs ^ ((row >> 2) & 3);
+  int gr = r0 + row;
+  gr = gr < R ? gr : R - 1;
+  glds16(base + (long)gr * ld + k0 + c * 8, tile + 1024 * j);
+}
+
 template <int ROWS, int NW = 8>
 __device__ __forceinline__ void v3_stage_kn(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
                                             int wave, int lane) {
@@ -398,30 +509,30 @@ __device__ __forceinline__ void v3_stage_kn(char* tile, const __bf16* __restrict
   for (int i = 0; i < (TI + NW - 1) / NW; ++i) {
     const int j = wave + NW * i;
     if (j >= TI) break;  // (192-row tiles: waves 4-7 issue one instruction less)
-    const int row = 16 * j + (lane >> 2), cs = lane & 3;
-    const int c = cs ^ ((row >> 2) & 3);
-    int gr = r0 + row;
-    gr = gr < R ? gr : R - 1;
-    glds16(base + (long)gr * ld + k0 + c * 8, tile + 1024 * j);
+    v3_piece_kn(tile, base, ld, r0, R, k0, j, lane);
   }
+}
+
+// One piece j of a k-major tile (COLS columns: 1024 / (2 COLS) k-rows per piece).
+template <int COLS>
+__device__ __forceinline__ void v3_piece_km(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
+                                            int j, int lane) {
+  constexpr int RB = COLS * 2;         // bytes per k-row
+  constexpr int KPI = 1024 / RB;       // k-rows per wave-instruction (2 or 4)
+  constexpr int CPR = RB / 16;         // chunks per k-row
+  const int krow = KPI * j + lane / CPR, cs = lane % CPR;
+  const int c = cs ^ ((krow & 3) << 2);
+  int gc = r0 + c * 8;
+  gc = gc < R ? gc : R - 8;
+  glds16(base + (long)(k0 + krow) * ld + gc, tile + 1024 * j);
 }
 
 template <int COLS, int NW = 8>
 __device__ __forceinline__ void v3_stage_km(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
                                             int wave, int lane) {
-  constexpr int RB = COLS * 2;         // bytes per k-row
-  constexpr int KPI = 1024 / RB;       // k-rows per wave-instruction (2 or 4)
-  constexpr int CPR = RB / 16;         // chunks per k-row
-  constexpr int NI = 32 * RB / 1024 / NW;
+  constexpr int NI = 32 * COLS * 2 / 1024 / NW;
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int j = wave + NW * i;
-    const int krow = KPI * j + lane / CPR, cs = lane % CPR;
-    const int c = cs ^ ((krow & 3) << 2);
-    int gc = r0 + c * 8;
-    gc = gc < R ? gc : R - 8;
-    glds16(base + (long)(k0 + krow) * ld + gc, tile + 1024 * j);
-  }
+  for (int i = 0; i < NI; ++i) v3_piece_km<COLS>(tile, base, ld, r0, R, k0, wave + NW * i, lane);
 }
 
 __device__ __forceinline__ Frag16 v3_frag_kn(const char* tile, int rb, int kk, int lane) {
@@ -459,7 +570,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false, bool DM = false,
-          int NW = 8>
+          int NW = 8, bool SWP = false>
 __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
   constexpr int TM = BM_ / WM, TN = BN_ / WN;      // per-wave tile
   constexpr int MT = TM / 32, NTL = TN / 32;       // 32x32 accumulators per wave
@@ -468,13 +579,26 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
   constexpr int G = (SB / 1024 + NW - 1) / NW;     // LDS-DMA instructions per wave per stage (max over waves)
   constexpr int D = STAGES - 1;                    // stages in flight
   static_assert(WM * WN == NW && (NW == 8 || (NW == 4 && !PP)) && (WB % (1024 * NW)) == 0 &&
-                    ((XB % (1024 * NW)) == 0 || (PP && !XK && XB == 12288 && DIRECT)),
+                    ((XB % (1024 * NW)) == 0 || ((PP || SWP) && !XK && XB == 12288 && DIRECT)),
                 "NW waves (ping-pong: 8); whole wave-instructions per wave, except the 192-row k-normal X tile of the "
                 "ping-pong kernel");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+#ifdef PM_GEMM_STAMP
+  const unsigned long long stamp_entry = __builtin_readcyclecounter();
+  unsigned long long stamp_loop_end = 0;
+  auto stamp_finish = [&]() {
+    const unsigned long long t_issued = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_acked = __builtin_readcyclecounter();
+    if (a.stamps && lane == 0 && blockIdx.y == 0) {
+      unsigned long long* o = a.stamps + ((long)blockIdx.x * NW + wave) * 16;
+      o[8] = stamp_entry; o[9] = stamp_loop_end; o[10] = t_issued; o[11] = t_acked;
+    }
+  };
+#endif
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = tile / a.tiles_n, tn = tile % a.tiles_n;
   const int m0 = tm * BM_, n0 = tn * BN_;
@@ -534,7 +658,120 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  if constexpr (!PP) {
+  if constexpr (SWP) {
+    // Software-pipelined loop, one barrier per k-step.  Iteration t runs the MFMAs of stage t on fragments that were
+    // read from LDS during iteration t-1, and between those MFMAs issues (a) the fragment reads of stage t+1 into the
+    // other register set and (b) this wave's LDS-DMA pieces of stage t+3 into the slot of stage t-1 (every wave
+    // consumed its stage-(t-1) fragments before it reached this iteration's barrier).  LDS reads and DMA issue cost
+    // far less in the shadow of the wave's own MFMAs than in a phase of their own (stamped: 12 ds_read_b128 276 cyc,
+    // 4 pieces 416 cyc in the ping-pong read phase), and the SIMD's two waves cover each other's remaining stalls.
+    // Ring of STAGES slots: the pieces of stage t+STAGES-1 go into the slot of stage t-1; stages t+2 .. t+STAGES-2
+    // may still be in flight at the barrier of iteration t (STAGES = 3: none -- the block's twin on the CU covers it).
+    static_assert((STAGES == 4 || STAGES == 3) && !PP, "software-pipelined ring: 3 or 4 slots");
+    constexpr int AHEAD = STAGES - 1;   // issue distance
+    constexpr int FLY = STAGES - 3;     // stages allowed in flight across the barrier
+    constexpr int TIX = XB / 1024, TIW = WB / 1024;         // DMA pieces per side per stage
+    constexpr int GX = (TIX + NW - 1) / NW, GW = TIW / NW;  // per wave (GX: max over waves)
+    constexpr int NR = 2 * (NTL + MT), NMF = 2 * NTL * MT;  // fragment reads / MFMAs per k-step
+    constexpr int PER = NMF / (GX + GW);                    // one DMA piece every PER MFMAs
+    static_assert(GX + GW == G && NR <= NMF && PER >= 2, "interleave plan");
+    constexpr bool UNEVEN = (TIX % NW) != 0;
+    const int gq = wave >> 2;
+    auto wait_stages = [&](auto n) {  // all but the n youngest stages of this wave's pieces have landed
+      constexpr int N = decltype(n)::value;
+      if constexpr (UNEVEN) {
+        if (gq == 0) wait_vmcnt<N * G>(); else wait_vmcnt<N * (G - 1)>();
+      } else {
+        wait_vmcnt<N * G>();
+      }
+    };
+    auto piece = [&](int t, int p) {
+      char* buf = smem + (t % STAGES) * SB;
+      const int k0 = t * V3_KE;
+      if (p < GX) {
+        const int j = wave + NW * p;
+        if (UNEVEN && j >= TIX) return;
+        if constexpr (XK) v3_piece_km<BM_>(buf, X, a.ldx, m0, a.M, k0, j, lane);
+        else v3_piece_kn(buf, X, a.ldx, m0, a.M, k0, j, lane);
+      } else {
+        const int j = wave + NW * (p - GX);
+        if constexpr (WK) v3_piece_km<BN_>(buf + XB, W, a.ldw, n0, a.N, k0, j, lane);
+        else v3_piece_kn(buf + XB, W, a.ldw, n0, a.N, k0, j, lane);
+      }
+    };
+    auto read_one = [&](int t, int q, Frag16 (&fw)[2][NTL], Frag16 (&fx)[2][MT]) {
+      const char* bx = smem + (t % STAGES) * SB;
+      const char* bw = bx + XB;
+      const int kk = q / (NTL + MT), r = q % (NTL + MT);
+      if (r < NTL) {
+        if constexpr (WK) fw[kk][r] = v3_frag_km<BN_ * 2>(bw, wn * TN + 32 * r, kk, lane);
+        else fw[kk][r] = v3_frag_kn(bw, wn * TN + 32 * r, kk, lane);
+      } else {
+        if constexpr (XK) fx[kk][r - NTL] = v3_frag_km<BM_ * 2>(bx, wm * TM + 32 * (r - NTL), kk, lane);
+        else fx[kk][r - NTL] = v3_frag_kn(bx, wm * TM + 32 * (r - NTL), kk, lane);
+      }
+    };
+#ifdef PM_GEMM_STAMP
+    unsigned long long stamp_t[8], stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
+    // FULL: stages t+1 and t+3 exist (steady state, no branches in the MFMA stream)
+    auto step =[&](auto full, int t, const Frag16 (&cw)[2][NTL], const Frag16 (&cx)[2][MT], Frag16 (&nw)[2][NTL],
+                    Frag16 (&nx)[2][MT]) {
+      constexpr bool FULL = decltype(full)::value;
+      PM_STAMP(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (FLY > 0 && (FULL || t + 2 < nk)) wait_stages(std::integral_constant<int, FLY>{});  // stage t+1 landed
+      else wait_vmcnt<0>();
+      PM_STAMP(1);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      PM_STAMP(2);
+      const bool rd = FULL || t + 1 < nk, ld = FULL || t + AHEAD < nk;
+#pragma unroll
+      for (int m = 0; m < NMF; ++m) {
+        const int kk = m / (NTL * MT), i = (m / MT) % NTL, j = m % MT;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cw[kk][i].h, cx[kk][j].h, acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (m < NR && rd) read_one(t + 1, m, nw, nx);
+        if ((m % PER) == 1 && m / PER < G && ld) piece(t + AHEAD, m / PER);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef PM_GEMM_STAMP
+        if (m == NMF / 2 - 1) PM_STAMP(3);
+#endif
+      }
+#ifdef PM_GEMM_STAMP
+      PM_STAMP(4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stamp_acc[i] += stamp_t[i + 1] - stamp_t[i];
+#endif
+    };
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t)
+      if (t < nk) issue(t);
+    if (nk > 2) wait_stages(std::integral_constant<int, (AHEAD > 2 ? 2 : 1)>{});
+    else if (nk > 1) wait_stages(std::integral_constant<int, 1>{});
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    Frag16 fwA[2][NTL], fxA[2][MT], fwB[2][NTL], fxB[2][MT];
+    read_frags(0, fwA, fxA);
+    __builtin_amdgcn_sched_barrier(0);
+    int t = 0;
+    for (; t + 1 + AHEAD < nk; t += 2) {
+      step(std::true_type{}, t, fwA, fxA, fwB, fxB);
+      step(std::true_type{}, t + 1, fwB, fxB, fwA, fxA);
+    }
+    for (; t < nk; t += 2) {
+      step(std::false_type{}, t, fwA, fxA, fwB, fxB);
+      if (t + 1 < nk) step(std::false_type{}, t + 1, fwB, fxB, fwA, fxA);
+    }
+#ifdef PM_GEMM_STAMP
+    if (a.stamps && lane == 0 && blockIdx.y == 0) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) a.stamps[((long)blockIdx.x * NW + wave) * 16 + i] = stamp_acc[i];
+      a.stamps[((long)blockIdx.x * NW + wave) * 16 + 7] = nk;
+    }
+#endif
+  } else if constexpr (!PP) {
 #pragma unroll
     for (int t = 0; t < D; ++t)
       if (t < nk) issue(t);
@@ -592,19 +829,29 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
     else if (nk > 1) wait_one_stage_in_flight();
     else wait_vmcnt<0>();
     if (gq == 1) __builtin_amdgcn_s_barrier();
+#ifdef PM_GEMM_STAMP
+    unsigned long long stamp_t[8], stamp_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int t = 0; t < nk; ++t) {
+      PM_STAMP(0);
       __builtin_amdgcn_s_barrier();  // opens R_t
+      PM_STAMP(1);
       Frag16 fw[2][NTL], fx[2][MT];
       read_frags(t, fw, fx);
       __builtin_amdgcn_sched_barrier(0);
+      PM_STAMP(2);
       if constexpr (!DM) {
         if (t + DP < nk) issue(t + DP);
       }
+      PM_STAMP(3);
       if (t + 2 < nk) wait_one_stage_in_flight();  // stage t+1 landed, stage t+2 may fly
       else wait_vmcnt<0>();
+      PM_STAMP(4);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      PM_STAMP(5);
       __builtin_amdgcn_s_barrier();  // opens M_t
+      PM_STAMP(6);
       if constexpr (DM) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -624,29 +871,125 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
       } else {
         mma_all(fw, fx);
       }
+#ifdef PM_GEMM_STAMP
+      PM_STAMP(7);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) stamp_acc[i] += stamp_t[i + 1] - stamp_t[i];
+#endif
     }
+#ifdef PM_GEMM_STAMP
+    if (a.stamps && lane == 0 && blockIdx.y == 0) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) a.stamps[((long)blockIdx.x * NW + wave) * 16 + i] = stamp_acc[i];
+      a.stamps[((long)blockIdx.x * NW + wave) * 16 + 7] = nk;
+    }
+#endif
     if (gq == 0) __builtin_amdgcn_s_barrier();
   }
+#ifdef PM_GEMM_STAMP
+  stamp_loop_end = __builtin_readcyclecounter();
+#endif
   const int h = lane >> 5;
   const int epi = a.epilogue;
   if constexpr (DIRECT) {
     // straight from registers (lane = row m, register quad = 4 consecutive n): no LDS, no block barrier -- the
     // stores drain while the CU's other resident block keeps the MFMA pipe busy
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-      const int m = m0 + wm * TM + j * 32 + (lane & 31);
-      if (m >= a.M) continue;
+    if (a.c_dtype == PM_BF16 && epi != PM_EPI_RESIDUAL && epi != PM_EPI_ACCUM && (a.N & 7) == 0 && (a.ldc & 7) == 0) {
+      // act-typed output: lanes l and l+32 (same row m, columns 8g+4h) trade 4-vectors so that each holds 8
+      // consecutive columns -> 16-B stores
+      constexpr int NV8 = NTL * 2;
+      long noff8[NV8];
+      bool nok8[NV8];
+      f32x4 b0[NV8], b1[NV8];
 #pragma unroll
       for (int i = 0; i < NTL; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * TN + i * 32 + 8 * g + 4 * h;
-          if (n >= a.N) continue;
-          f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-          epilogue4<__bf16>(a, epi, (long)m * a.ldc + n, v);
+        for (int p = 0; p < 2; ++p) {
+          const int n = n0 + wn * TN + i * 32 + 16 * p + 8 * h;
+          nok8[i * 2 + p] = n < a.N;
+          noff8[i * 2 + p] = n < a.N ? n : a.N - 8;
         }
+#pragma unroll
+      for (int e = 0; e < NV8; ++e) {
+        b0[e] = b1[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+          b0[e] = *reinterpret_cast<const f32x4*>(a.bias + noff8[e]);
+          b1[e] = *reinterpret_cast<const f32x4*>(a.bias + noff8[e] + 4);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * TM + j * 32 + (lane & 31);
+        const bool mok = m < a.M;
+        const long row = (long)(mok ? m : a.M - 1) * a.ldc;
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) {
+          long off[2];
+          bool ok[2];
+          f32x4 lo[2], hi[2];
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int e = i * 2 + p;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float x = acc[i][j][8 * p + k], y = acc[i][j][8 * p + 4 + k];
+              swap_halves(x, y);
+              lo[p][k] = x + b0[e][k];
+              hi[p][k] = y + b1[e][k];
+            }
+            off[p] = row + noff8[e];
+            ok[p] = mok && nok8[e];
+          }
+          epilogue_batch8<2>(a, epi, off, ok, lo, hi);
+        }
+      }
+#ifdef PM_GEMM_STAMP
+      stamp_finish();
+#endif
+      return;
     }
+    constexpr int NV = NTL * 4;
+    long noff[NV];
+    bool nok[NV];
+    f32x4 bv[NV];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * TN + i * 32 + 8 * g + 4 * h;
+        nok[i * 4 + g] = n < a.N;
+        noff[i * 4 + g] = n < a.N ? n : a.N - 4;
+      }
+    if (a.bias) {
+#pragma unroll
+      for (int e = 0; e < NV; ++e) bv[e] = *reinterpret_cast<const f32x4*>(a.bias + noff[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < NV; ++e) bv[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int m = m0 + wm * TM + j * 32 + (lane & 31);
+      const bool mok = m < a.M;
+      const long row = (long)(mok ? m : a.M - 1) * a.ldc;
+#pragma unroll
+      for (int i = 0; i < NTL; ++i) {  // 4 vectors (one 32x32 accumulator row) per batch
+        long off[4];
+        bool ok[4];
+        f32x4 v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int e = i * 4 + g;
+          off[g] = row + noff[e];
+          ok[g] = mok && nok[e];
+          v[g] = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + bv[e];
+        }
+        epilogue_batch<4>(a, epi, off, ok, v);
+      }
+    }
+#ifdef PM_GEMM_STAMP
+    stamp_finish();
+#endif
     return;
   }
   __syncthreads();  // all ring slots dead: reuse LDS for the epilogue staging
@@ -669,21 +1012,65 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
       const int mw = m0 + wm * TM + mh * 64, nw = n0 + wn * TN + nh * 64;
-#pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
-        const int ml = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
-        const int m = mw + ml, n = nw + c4;
-        if (m >= a.M || n >= a.N) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(st + ml * STAGE_ROW + c4 * 4);
-        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-        epilogue4<__bf16>(a, epi, (long)m * a.ldc + n, v);
+      if (a.c_dtype == PM_BF16 && epi != PM_EPI_RESIDUAL && epi != PM_EPI_ACCUM && (a.N & 7) == 0 && (a.ldc & 7) == 0) {
+        // act-typed output: 8 columns per lane -> 16-B stores (8 rows x 128 B per wave instruction)
+        const int c8 = (lane & 7) * 8, n8 = nw + c8;
+        const bool nok8 = n8 < a.N;
+        const long ncl8 = nok8 ? n8 : a.N - 8;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (a.bias) {
+          b0 = *reinterpret_cast<const f32x4*>(a.bias + ncl8);
+          b1 = *reinterpret_cast<const f32x4*>(a.bias + ncl8 + 4);
+        }
+#pragma unroll
+        for (int it4 = 0; it4 < 2; ++it4) {
+          long off[4];
+          bool ok[4];
+          f32x4 lo[4], hi[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int ml = (it4 * 4 + u) * 8 + (lane >> 3);
+            const int m = mw + ml;
+            ok[u] = m < a.M && nok8;
+            off[u] = (long)(m < a.M ? m : a.M - 1) * a.ldc + ncl8;
+            lo[u] = *reinterpret_cast<const f32x4*>(st + ml * STAGE_ROW + c8 * 4) + b0;
+            hi[u] = *reinterpret_cast<const f32x4*>(st + ml * STAGE_ROW + c8 * 4 + 16) + b1;
+          }
+          epilogue_batch8<4>(a, epi, off, ok, lo, hi);
+        }
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
+      const int c4 = (lane & 15) * 4, n = nw + c4;
+      const bool nok = n < a.N;
+      const long ncl = nok ? n : a.N - 4;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + ncl);
+#pragma unroll
+      for (int it4 = 0; it4 < 4; ++it4) {  // 4 rows x 4 batches of 4: loads of a batch overlap
+        long off[4];
+        bool ok[4];
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ml = (it4 * 4 + u) * 4 + (lane >> 4);
+          const int m = mw + ml;
+          ok[u] = m < a.M && nok;
+          off[u] = (long)(m < a.M ? m : a.M - 1) * a.ldc + ncl;
+          v[u] = *reinterpret_cast<const f32x4*>(st + ml * STAGE_ROW + c4 * 4) + bv;
+        }
+        epilogue_batch<4>(a, epi, off, ok, v);
       }
       __builtin_amdgcn_wave_barrier();
     }
   }
+#ifdef PM_GEMM_STAMP
+  stamp_finish();
+#endif
 }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, bool DM = false, int NW = 8>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, bool DM = false, int NW = 8,
+          bool SWP = false>
 int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   a.tiles_m = (a.M + BM_ - 1) / BM_;
   a.tiles_n = (a.N + BN_ - 1) / BN_;
@@ -692,11 +1079,11 @@ int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   const size_t lds = ring > stage ? ring : stage;
   const dim3 grid(a.tiles_m * a.tiles_n), block(NW * 64);
   if (wk) {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP, false, DM, NW>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP, false, DM, NW, SWP>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP, false, DM, NW>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP, false, DM, NW, SWP>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   }
@@ -759,6 +1146,10 @@ int g_force_cfg = 0;  // tuning hook (not part of the ABI): 0 auto, 1 = 128x128 
 }  // namespace
 
 extern "C" void pm_debug_gemm_config(int cfg) { g_force_cfg = cfg; }
+#ifdef PM_GEMM_STAMP
+namespace { unsigned long long* g_stamps = nullptr; }
+extern "C" void pm_debug_gemm_stamps(void* p) { g_stamps = reinterpret_cast<unsigned long long*>(p); }
+#endif
 
 extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
                           const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux,
@@ -786,6 +1177,9 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
   a.tiles_m = (M + BM - 1) / BM;
   a.tiles_n = (N + BN - 1) / BN;
   a.split_k = 1;
+#ifdef PM_GEMM_STAMP
+  a.stamps = g_stamps;
+#endif
   hipStream_t s = pm_stream(stream);
   const int ke = in_dtype == PM_BF16 ? 64 : 32;
   const bool fast = (K % ke) == 0;
@@ -808,6 +1202,8 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
         const long nt = (N + 255) / 256;
         const long c256 = (((M + 255) / 256 * nt + 255) / 256) * 256, c192 = (((M + 191) / 192 * nt + 255) / 256) * 192;
         if (c192 < c256) cfg = 10;
+        // f32 residual outputs of the forward (k-normal W): the software-pipelined loop wins (fc2 80 -> 70 us)
+        if (epilogue == PM_EPI_RESIDUAL && !b_kmajor) cfg = cfg == 10 ? 26 : 25;
       }
     }
     switch (cfg) {
@@ -829,6 +1225,14 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
       case 19: return launch_v3<256, 128, 2, 2, 3, 2, false, false, false, 4>(a, b_kmajor, s);
       case 20: return launch_v3<128, 128, 2, 2, 3, 3, true, false, false, 4>(a, b_kmajor, s);
       case 21: return launch_v3<128, 128, 2, 2, 4, 2, true, false, false, 4>(a, b_kmajor, s);
+      // software-pipelined loop (fragment reads and DMA issue between the wave's own MFMAs)
+      case 27: return launch_v3<128, 256, 2, 2, 3, 2, true, false, false, 4, true>(a, b_kmajor, s);   // two 4-wave blocks / CU
+      case 28: return launch_v3<128, 256, 2, 2, 3, 2, false, false, false, 4, true>(a, b_kmajor, s);
+      case 29: return launch_v3<256, 128, 2, 2, 3, 2, true, false, false, 4, true>(a, b_kmajor, s);
+      case 30: return launch_v3<256, 128, 2, 2, 3, 2, false, false, false, 4, true>(a, b_kmajor, s);
+      case 24: return launch_v3<256, 256, 2, 4, 4, 2, false, false, false, 8, true>(a, b_kmajor, s);
+      case 25: return launch_v3<256, 256, 2, 4, 4, 2, true, false, false, 8, true>(a, b_kmajor, s);
+      case 26: return launch_v3<192, 256, 2, 4, 4, 2, true, false, false, 8, true>(a, b_kmajor, s);
       default: return launch_v3<256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
     }
   }
