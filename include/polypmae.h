@@ -169,6 +169,14 @@ int pm_adamw_dev(float* p, const float* g, float* m, float* v, void* shadow, int
  * (the device-side counterpart of tc.py:1437-1454 _compute_grad_norm and misc.py:387-400 detect_grad_anomalies). */
 int pm_grad_stats(const float* g, long n, float* out, void* stream);
 
+/* Process-wide tuning knobs (no reference counterpart; defaults are the stand-alone optimum).  Returns the previous
+ * value, or PM_EINVAL for an unknown knob / out-of-range value.
+ *   PM_TUNE_WGRAD_BLOCKS: workgroups a split-K weight-gradient GEMM (both operands k-major) spreads over.  256 = the
+ *     whole chip (fastest alone); a caller that runs weight gradients on a second stream beside the dgrad chain sets
+ *     ~128 so that the chain keeps half of the CUs (the training engine does: +4.5 % step rate). */
+enum { PM_TUNE_WGRAD_BLOCKS = 1 };
+int pm_tune(int knob, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,7 +43,10 @@ SIGNATURES = {
     "pm_adamw_tick": [P, I, P],
     "pm_adamw_dev": [P, P, P, P, P, I, L, P, P],
     "pm_grad_stats": [P, L, P, P],
+    "pm_tune": [I, I],
 }
+
+TUNE_WGRAD_BLOCKS = 1
 
 _lib = None
 

@@ -1091,12 +1091,13 @@ int launch_v3(GemmArgs a, int wk, hipStream_t s) {
 }
 
 // wgrad shape (both operands k-major, K = #tokens): 256x128 ping-pong ring kernel, direct epilogue, split-K slabs
+template <int BM_, int BN_, int WM, int WN, bool SWP>
 int launch_v3_wgrad(GemmArgs a, hipStream_t s) {
-  a.tiles_m = (a.M + 255) / 256;
-  a.tiles_n = (a.N + 127) / 128;
-  constexpr int ring = 4 * (256 + 128) * 64;
+  a.tiles_m = (a.M + BM_ - 1) / BM_;
+  a.tiles_n = (a.N + BN_ - 1) / BN_;
+  constexpr int ring = 4 * (BM_ + BN_) * 64;
   const dim3 grid(a.tiles_m * a.tiles_n, a.split_k), block(512);
-  auto kern = gemm_v3_kernel<256, 128, 4, 2, true, 4, 2, true, true, true>;
+  auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, 4, 2, true, !SWP, true, false, 8, SWP>;
   PM_ALLOW_LDS(kern, ring);
   hipLaunchKernelGGL(kern, grid, block, ring, s, a);
   return pm_check_launch();
@@ -1141,11 +1142,22 @@ int launch_glds(const GemmArgs& a, int xk, int wk, hipStream_t s) {
   return pm_check_launch();
 }
 
+int g_wgrad_blocks = 256;  // pm_tune(PM_TUNE_WGRAD_BLOCKS)
 int g_force_cfg = 0;  // tuning hook (not part of the ABI): 0 auto, 1 = 128x128 kernels only, 2 = 256x128, 3 = 256x256
 
 }  // namespace
 
 extern "C" void pm_debug_gemm_config(int cfg) { g_force_cfg = cfg; }
+
+extern "C" int pm_tune(int knob, int value) {
+  if (knob == PM_TUNE_WGRAD_BLOCKS) {
+    if (value < 16 || value > 1024) return PM_EINVAL;
+    const int prev = g_wgrad_blocks;
+    g_wgrad_blocks = value;
+    return prev;
+  }
+  return PM_EINVAL;
+}
 #ifdef PM_GEMM_STAMP
 namespace { unsigned long long* g_stamps = nullptr; }
 extern "C" void pm_debug_gemm_stamps(void* p) { g_stamps = reinterpret_cast<unsigned long long*>(p); }
@@ -1245,9 +1257,15 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
   // large-K wgrad on the ping-pong ring kernel: 256x128 tiles, split so that tiles x splits ~ one block per CU
   if (splittable && in_dtype == PM_BF16 && a_kmajor && b_kmajor && (K % V3_KE) == 0 && K >= 2048 && M >= 256 && N >= 128 &&
       (g_force_cfg & 63) != 1) {
-    const int t3 = ((M + 255) / 256) * ((N + 127) / 128);
+    // 256x256 tiles (twice the MFMAs per barrier) once there are enough of them to split K over the chip
+    // (qkv / fc1 / fc2 gradients: 27-36 tiles, 74 us vs 83); 256x128 for the small 768x768 projection gradient.
+    // Tuning hook bits 6-7: 1 = force 256x128, 2 = force 256x256, 3 = software-pipelined 256x256 (slower: tr reads).
+    int wv = (g_force_cfg >> 6) & 3;
+    if (wv == 0) wv = ((M + 255) / 256) * ((N + 255) / 256) >= 24 ? 2 : 1;
+    const int bn3 = wv >= 2 ? 256 : 128;
+    const int t3 = ((M + 255) / 256) * ((N + bn3 - 1) / bn3);
     const int nk3 = K / V3_KE;
-    int split = 256 / t3;
+    int split = g_wgrad_blocks / t3;
     if (split > nk3 / 16) split = nk3 / 16;
     if (split > 16) split = 16;
     if (split < 1) split = 1;
@@ -1260,7 +1278,9 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
       w.C = workspace;
       w.epilogue = PM_EPI_STORE;
     }
-    const int st = launch_v3_wgrad(w, s);
+    const int st = wv == 1   ? launch_v3_wgrad<256, 128, 4, 2, false>(w, s)
+                   : wv == 2 ? launch_v3_wgrad<256, 256, 2, 4, false>(w, s)
+                             : launch_v3_wgrad<256, 256, 2, 4, true>(w, s);
     if (st || w.split_k == 1) return st;
     const long nvec = (long)M * (N >> 2);
     int grid = (int)((nvec + 255) / 256);

@@ -62,6 +62,7 @@ class Kernels:
                                              _ptr(dgamma), _ptr(dbeta), _ptr(dcolsum), M, D, _ptr(ws), ws.numel(), _stream()),
                    "pm_layernorm_bwd")
 
+    WGRAD_BLOCKS = 128
     SPLITK_WS_BYTES = 96 << 20  # scratch for split-K wgrad slabs (16 x the largest weight of ViT-B would be 151 MB;
     #                             pm_gemm_ws picks the largest split that fits)
 
@@ -79,6 +80,9 @@ class Kernels:
         if st is None or st.device != device:
             st = torch.cuda.Stream(device=device)
             self._side = st
+            # the weight gradients run beside the dgrad chain: spread each over ~half of the CUs so that the chain
+            # (LayerNorm / attention backward, dgrad GEMMs) is not starved (measured: 128 best of 96..256)
+            _lib.check(min(self.lib.pm_tune(_lib.TUNE_WGRAD_BLOCKS, self.WGRAD_BLOCKS), 0), "pm_tune")
         return st
 
     def _workspace(self, device):
