@@ -77,6 +77,15 @@ int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, long ldb, i
                const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
                int M, int N, int K, void* workspace, size_t ws_bytes, void* stream);
 
+/* pm_gemm that also accumulates the column sums of the stored result: colsum[n] += sum_m C[m][n] (f32 [N]) -- the bias
+ * gradient of the Linear whose output gradient C is (reference: autograd of nn.Linear, e.g. Mlp.fc1.bias.grad from the
+ * dGELU dgrad).  Fused into the epilogue where the kernel in use supports it (act-typed C of the large-tile kernel;
+ * per-tile partial rows in `workspace`, reduced in a fixed order), otherwise pm_colsum_ws runs after the GEMM on the
+ * same stream.  No split-K on this entry point (dgrad / forward shapes). */
+int pm_gemm_colsum(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
+                   const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
+                   float* colsum, int M, int N, int K, void* workspace, size_t ws_bytes, void* stream);
+
 /* Fused multi-head self-attention core -- replaces timm Attention.forward between qkv and proj:
  * softmax(q k^T * dh^-0.5) v, never materialising the [N,N] scores in HBM.
  * qkv: act [B, N, 3, H, dh] (the qkv Linear's output as stored); out: act [B, N, H*dh];

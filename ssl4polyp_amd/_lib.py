@@ -23,6 +23,7 @@ SIGNATURES = {
     "pm_layernorm_bwd": [P, I, P, L, P, P, P, P, L, P, L, P, I, P, P, P, I, I, P, ctypes.c_size_t, P],
     "pm_gemm": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P],
     "pm_gemm_ws": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P],
+    "pm_gemm_colsum": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, P, I, I, I, P, ctypes.c_size_t, P],
     "pm_attention_fwd": [P, P, P, I, I, I, I, I, P],
     "pm_attention_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "pm_colsum": [P, L, I, P, I, I, P],

@@ -54,6 +54,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int split_k;       // >1: blockIdx.y = split, C = f32 slabs [split][M][ldc]
   int ksteps_split;  // k-steps per split
+  float* cs_partials;  // pm_gemm_colsum: per (row tile, wave row) column sums of the result [tiles_m * WM][N], or NULL
 #ifdef PM_GEMM_STAMP
   unsigned long long* stamps;  // diagnostic build only: per-wave cycle sums of the k-loop segments
 #endif
@@ -901,6 +902,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
       long noff8[NV8];
       bool nok8[NV8];
       f32x4 b0[NV8], b1[NV8];
+      float cs[NV8][8];
+#pragma unroll
+      for (int e = 0; e < NV8; ++e)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cs[e][k] = 0.f;
 #pragma unroll
       for (int i = 0; i < NTL; ++i)
 #pragma unroll
@@ -941,6 +947,33 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
             ok[p] = mok && nok8[e];
           }
           epilogue_batch8<2>(a, epi, off, ok, lo, hi);
+          if (a.cs_partials && mok) {  // column sums of what was stored (rows beyond M hold a clamped duplicate)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                cs[i * 2 + p][k] += lo[p][k];
+                cs[i * 2 + p][4 + k] += hi[p][k];
+              }
+          }
+        }
+      }
+      if (a.cs_partials) {
+        // sum over the 32 rows held by the lanes of each half-wave, then one 32-B row segment per (half, vector)
+        float* dst = a.cs_partials + (long)(tm * WM + wm) * a.N;
+#pragma unroll
+        for (int e = 0; e < NV8; ++e) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float v = cs[e][k];
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
+            cs[e][k] = v;
+          }
+          if ((lane & 31) == 0 && nok8[e]) {
+            *reinterpret_cast<f32x4*>(dst + noff8[e]) = f32x4{cs[e][0], cs[e][1], cs[e][2], cs[e][3]};
+            *reinterpret_cast<f32x4*>(dst + noff8[e] + 4) = f32x4{cs[e][4], cs[e][5], cs[e][6], cs[e][7]};
+          }
         }
       }
 #ifdef PM_GEMM_STAMP
@@ -1143,6 +1176,31 @@ int launch_glds(const GemmArgs& a, int xk, int wk, hipStream_t s) {
 }
 
 int g_wgrad_blocks = 256;  // pm_tune(PM_TUNE_WGRAD_BLOCKS)
+
+// pm_gemm_colsum -> pm_gemm_ws hand-off: the dispatcher fuses the column sums into the register epilogue of the
+// large-tile kernel when it picks that kernel (and the partial rows fit), and reports how many partial rows it wrote.
+struct ColsumRequest {
+  float* partials = nullptr;
+  size_t capacity = 0;  // bytes
+  int rows = 0;         // out: partial rows written (0 = not fused)
+};
+thread_local ColsumRequest g_cs_req;
+
+// out[n] += sum over the partial rows, fixed order
+__global__ __launch_bounds__(1024) void gemm_colsum_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out,
+                                                                  int rows, int N) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  red[rg][lane] = n < N ? strided_sum<8>(partials + n, N, rg, 16, rows) : 0.f;
+  __syncthreads();
+  if (rg == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][lane];
+    out[n] += t;
+  }
+}
 int g_force_cfg = 0;  // tuning hook (not part of the ABI): 0 auto, 1 = 128x128 kernels only, 2 = 256x128, 3 = 256x256
 
 }  // namespace
@@ -1189,6 +1247,7 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
   a.tiles_m = (M + BM - 1) / BM;
   a.tiles_n = (N + BN - 1) / BN;
   a.split_k = 1;
+  a.cs_partials = nullptr;
 #ifdef PM_GEMM_STAMP
   a.stamps = g_stamps;
 #endif
@@ -1216,6 +1275,14 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
         if (c192 < c256) cfg = 10;
         // f32 residual outputs of the forward (k-normal W): the software-pipelined loop wins (fc2 80 -> 70 us)
         if (epilogue == PM_EPI_RESIDUAL && !b_kmajor) cfg = cfg == 10 ? 26 : 25;
+      }
+    }
+    if ((cfg == 9 || cfg == 10) && g_cs_req.partials && c_dtype == PM_BF16 && (N & 7) == 0 && (ldc & 7) == 0 &&
+        (epilogue == PM_EPI_STORE || epilogue == PM_EPI_DGELU)) {
+      const int rows = ((M + (cfg == 9 ? 255 : 191)) / (cfg == 9 ? 256 : 192)) * 2;  // tiles_m x WM
+      if ((size_t)rows * N * sizeof(float) <= g_cs_req.capacity) {
+        a.cs_partials = g_cs_req.partials;
+        g_cs_req.rows = rows;
       }
     }
     switch (cfg) {
@@ -1311,6 +1378,27 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
     }
   }
   return in_dtype == PM_BF16 ? launch_glds<__bf16>(a, a_kmajor, b_kmajor, s) : launch_glds<float>(a, a_kmajor, b_kmajor, s);
+}
+
+extern "C" int pm_gemm_colsum(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
+                              const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux,
+                              const float* resid, float* colsum, int M, int N, int K, void* workspace, size_t ws_bytes,
+                              void* stream) {
+  if (!colsum) return PM_EINVAL;
+  g_cs_req.partials = reinterpret_cast<float*>(workspace);
+  g_cs_req.capacity = workspace ? ws_bytes : 0;
+  g_cs_req.rows = 0;
+  const int st = pm_gemm_ws(A, lda, a_kmajor, B, ldb, b_kmajor, in_dtype, bias, C, ldc, c_dtype, epilogue, aux, resid, M, N, K,
+                            nullptr, 0, stream);
+  const int rows = g_cs_req.rows;
+  g_cs_req = ColsumRequest{};
+  if (st) return st;
+  if (rows > 0) {
+    hipLaunchKernelGGL(gemm_colsum_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, pm_stream(stream),
+                       reinterpret_cast<const float*>(workspace), colsum, rows, N);
+    return pm_check_launch();
+  }
+  return pm_colsum_ws(C, ldc, c_dtype, colsum, M, N, workspace, ws_bytes, stream);
 }
 
 extern "C" int pm_gemm(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,

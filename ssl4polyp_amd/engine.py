@@ -18,6 +18,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -63,6 +65,10 @@ class Kernels:
                    "pm_layernorm_bwd")
 
     WGRAD_BLOCKS = 128
+    # fc1.bias gradient inside the dGELU dgrad epilogue (pm_gemm_colsum) instead of a column-sum kernel on the side
+    # stream.  Off: the HBM-bound column sum overlaps the MFMA-bound GEMMs for free, while the fused reduction
+    # lengthens the dgrad chain (measured -2.5 % step rate when fused).
+    FUSE_COLSUM = os.environ.get("PM_FUSE_COLSUM", "0") == "1"
     SPLITK_WS_BYTES = 96 << 20  # scratch for split-K wgrad slabs (16 x the largest weight of ViT-B would be 151 MB;
     #                             pm_gemm_ws picks the largest split that fits)
 
@@ -92,10 +98,16 @@ class Kernels:
             self._ws = ws
         return ws
 
-    def gemm(self, A, lda, a_kmajor, B, ldb, b_kmajor, bias, C, ldc, epilogue, M, N, K, aux=None, resid=None):
+    def gemm(self, A, lda, a_kmajor, B, ldb, b_kmajor, bias, C, ldc, epilogue, M, N, K, aux=None, resid=None, colsum=None):
         in_dtype = _lib.dtype_code(A.dtype)
         if _lib.dtype_code(B.dtype) != in_dtype:
             raise _lib.PolypMaeError("pm_gemm: operand dtypes differ")
+        if colsum is not None:  # colsum[n] += sum_m C[m][n], fused into the epilogue where the kernel supports it
+            ws = self._colsum_workspace(A.device)
+            _lib.check(self.lib.pm_gemm_colsum(_ptr(A), lda, int(a_kmajor), _ptr(B), ldb, int(b_kmajor), in_dtype, _ptr(bias),
+                                               _ptr(C), ldc, _lib.dtype_code(C.dtype), epilogue, _ptr(aux), _ptr(resid),
+                                               _ptr(colsum), M, N, K, _ptr(ws), ws.numel(), _stream()), "pm_gemm_colsum")
+            return
         ws = self._workspace(A.device) if (a_kmajor and b_kmajor) else None
         _lib.check(self.lib.pm_gemm_ws(_ptr(A), lda, int(a_kmajor), _ptr(B), ldb, int(b_kmajor), in_dtype, _ptr(bias),
                                        _ptr(C), ldc, _lib.dtype_code(C.dtype), epilogue, _ptr(aux), _ptr(resid), M, N, K,
@@ -105,22 +117,26 @@ class Kernels:
         """out[M,N] = x[M,K] @ W[N,K]^T + bias  (nn.Linear forward)."""
         self.gemm(x, K, 0, W, K, 0, bias, out, N, epilogue, M, N, K, aux=aux, resid=resid)
 
-    def linear_dgrad(self, dy, W, dx, M, N_out, K_in, epilogue=EPI_STORE, aux=None):
-        """dx[M,K_in] = dy[M,N_out] @ W[N_out,K_in]  (W read as stored: k-major B operand)."""
-        self.gemm(dy, N_out, 0, W, K_in, 1, None, dx, K_in, epilogue, M, K_in, N_out, aux=aux)
+    def linear_dgrad(self, dy, W, dx, M, N_out, K_in, epilogue=EPI_STORE, aux=None, colsum=None):
+        """dx[M,K_in] = dy[M,N_out] @ W[N_out,K_in]  (W read as stored: k-major B operand); colsum += column sums of dx."""
+        self.gemm(dy, N_out, 0, W, K_in, 1, None, dx, K_in, epilogue, M, K_in, N_out, aux=aux, colsum=colsum)
 
     def linear_wgrad(self, dy, x, dW, M, N_out, K_in, accumulate):
         """dW[N_out,K_in] (+)= dy[M,N_out]^T @ x[M,K_in]  (both operands k-major, f32 output)."""
         self.gemm(dy, N_out, 1, x, K_in, 1, None, dW, K_in, EPI_ACCUM if accumulate else EPI_STORE, N_out, K_in, M)
 
-    def colsum(self, x, out, M, N):
+    def _colsum_workspace(self, device):
         # partial rows: one scratch per stream (main / wgrad side stream) so concurrent column sums never share it
         on_side = getattr(self, "_side", None) is not None and torch.cuda.current_stream() == self._side
         key = "_ws_cs_side" if on_side else "_ws_cs_main"
         ws = getattr(self, key, None)
-        if ws is None or ws.device != x.device:
-            ws = torch.empty(128 * 4096 * 4, dtype=torch.uint8, device=x.device)
+        if ws is None or ws.device != device:
+            ws = torch.empty(8 << 20, dtype=torch.uint8, device=device)
             setattr(self, key, ws)
+        return ws
+
+    def colsum(self, x, out, M, N):
+        ws = self._colsum_workspace(x.device)
         _lib.check(self.lib.pm_colsum_ws(_ptr(x), N, _lib.dtype_code(x.dtype), _ptr(out), M, N, _ptr(ws), ws.numel(),
                                          _stream()), "pm_colsum")
 
@@ -275,12 +291,16 @@ class BlockStack:
                 fork()
                 with torch.cuda.stream(side):
                     k.linear_wgrad(dx_act, bw.h_act, gr["mlp.fc2.weight"], M, D, Hd, accumulate("mlp.fc2.weight", i))
-            k.linear_dgrad(dx_act, p["mlp.fc2.weight"], d_hidden, M, D, Hd, EPI_DGELU, aux=bw.h_pre)
+            # fc1.bias gradient = column sums of d_hidden: optionally fused into the dGELU epilogue that produces it
+            fuse_cs = tr and k.FUSE_COLSUM
+            k.linear_dgrad(dx_act, p["mlp.fc2.weight"], d_hidden, M, D, Hd, EPI_DGELU, aux=bw.h_pre,
+                           colsum=gr["mlp.fc1.bias"] if fuse_cs else None)
             if tr:
                 fork()
                 with torch.cuda.stream(side):
                     k.linear_wgrad(d_hidden, bw.ln2, gr["mlp.fc1.weight"], M, Hd, D, accumulate("mlp.fc1.weight", i))
-                    k.colsum(d_hidden, gr["mlp.fc1.bias"], M, Hd)
+                    if not fuse_cs:
+                        k.colsum(d_hidden, gr["mlp.fc1.bias"], M, Hd)
             k.linear_dgrad(d_hidden, p["mlp.fc1.weight"], ws.d_ln, M, Hd, D)
             k.layernorm_bwd(ws.d_ln, bw.x_mid, p["norm2.weight"], bw.mean2, bw.rstd2, dx, dmid, dmid_act,
                             gr["norm2.weight"] if tr else None, gr["norm2.bias"] if tr else None,

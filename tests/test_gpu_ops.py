@@ -202,6 +202,37 @@ def test_gemm_large_tile_paths(M, N, K, layout, epi):
         assert rel(C.float(), p32.grad) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K,layout,epi", [
+    (4000, 3072, 768, "nn", "dgelu"),    # dGELU dgrad: fused into the 256-row register epilogue (fc1.bias gradient)
+    (4000 + 7, 768, 2304, "nn", "store"),  # 192-row tiles, ragged last tile
+    (300, 512, 256, "nn", "store"),      # small M: not the large-tile kernel -> pm_colsum_ws after the GEMM
+    (4000, 2304, 768, "nt", "store")])   # LDS-staged epilogue (no fused sums) -> fallback
+def test_gemm_colsum(M, N, K, layout, epi):
+    """pm_gemm_colsum: colsum[n] += sum_m C[m][n] next to the GEMM result, fused or by the fallback kernel."""
+    from ssl4polyp_amd._lib import EPI_DGELU, EPI_STORE
+    k = _k("bf16")
+    bf = torch.bfloat16
+    A, B = rnd(M, K, seed=80, scale=0.5).to(bf), rnd(N, K, seed=81, scale=0.5).to(bf)
+    acc = A.float() @ B.float().t()
+    b_mat, ldb, bkm = (B, K, 0) if layout == "nt" else (B.t().contiguous(), N, 1)
+    C = torch.full((M, N), float("nan"), device=DEV, dtype=bf)
+    base = rnd(N, seed=82)
+    cs = base.clone()
+    if epi == "dgelu":
+        pre = rnd(M, N, seed=83).to(bf)
+        k.gemm(A, K, 0, b_mat, ldb, bkm, None, C, N, EPI_DGELU, M, N, K, aux=pre, colsum=cs)
+        p32 = pre.float().requires_grad_(True)
+        F.gelu(p32).backward(acc)
+        want = p32.grad
+    else:
+        k.gemm(A, K, 0, b_mat, ldb, bkm, None, C, N, EPI_STORE, M, N, K, colsum=cs)
+        want = acc
+    assert rel(C.float(), want) < 1e-2
+    # the sums are over what was stored (fused: before the bf16 rounding of C, fallback: after it)
+    assert rel(cs - base, want.sum(0)) < 2e-3
+    assert rel(cs - base, C.float().sum(0)) < 2e-3
+
+
 # ------------------------------------------------------------------------------------------------
 def _attn_ref(qkv, B, N, H, dh):
     q, k_, v = qkv.float().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
