@@ -106,10 +106,10 @@ def kernel_stats(model, step):
     orig = k.gemm
     rec = []
 
-    def timed(A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, aux=None, resid=None):
+    def timed(A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        orig(A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, aux=aux, resid=resid)
+        orig(A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, **kw)
         e1.record()
         rec.append((("tn" if akm else "n") + ("n" if bkm else "t"), M, N, K, e0, e1))
 
