@@ -563,6 +563,8 @@ __device__ __forceinline__ Frag16 v3_frag_km(const char* tile, int rb, int kk, i
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -570,8 +572,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false, bool DM = false,
-          int NW = 8, bool SWP = false>
+template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false, int NW = 8,
+          bool SWP = false>
 __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
   constexpr int TM = BM_ / WM, TN = BN_ / WN;      // per-wave tile
   constexpr int MT = TM / 32, NTL = TN / 32;       // 32x32 accumulators per wave
@@ -801,9 +803,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
     // (and waited lgkmcnt(0) on) at least two barriers ago.  Stage readiness: every wave waits for its own DMA share
     // of stage t+1 before the barrier that opens its M_t -- for the lagging half that barrier is the one that opens
     // the leading half's R_{t+1}.
-    // DM = false: R_t refills slot (t+2)%4 (2 stages in flight).  DM = true: the refill of slot (t+3)%4 is issued in
-    // M_t between the MFMAs (3 stages in flight; the read phase -- the critical one -- gets shorter).
-    constexpr int DP = DM ? STAGES - 1 : STAGES - 2;
+    // (Issuing the refill, or half of it, between the MFMAs of M_t instead was measured neutral to slightly worse:
+    // the stamped read phase shrinks from 810 to 392 cycles but the MFMA phase grows from 575 to 730.)
+    constexpr int DP = STAGES - 2;
     static_assert(STAGES == 4, "ping-pong ring tuned for 4 slots");
     const int gq = wave >> 2;
 #pragma unroll
@@ -819,15 +821,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
         wait_vmcnt<G>();
       }
     };
-    auto wait_two_stages_in_flight = [&]() {
-      if constexpr (UNEVEN) {
-        if (gq == 0) wait_vmcnt<2 * G>(); else wait_vmcnt<2 * G - 2>();
-      } else {
-        wait_vmcnt<2 * G>();
-      }
-    };
-    if (DM && nk > 2) wait_two_stages_in_flight();
-    else if (nk > 1) wait_one_stage_in_flight();
+    if (nk > 1) wait_one_stage_in_flight();
     else wait_vmcnt<0>();
     if (gq == 1) __builtin_amdgcn_s_barrier();
 #ifdef PM_GEMM_STAMP
@@ -841,9 +835,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
       read_frags(t, fw, fx);
       __builtin_amdgcn_sched_barrier(0);
       PM_STAMP(2);
-      if constexpr (!DM) {
-        if (t + DP < nk) issue(t + DP);
-      }
+      if (t + DP < nk) issue(t + DP);
       PM_STAMP(3);
       if (t + 2 < nk) wait_one_stage_in_flight();  // stage t+1 landed, stage t+2 may fly
       else wait_vmcnt<0>();
@@ -853,25 +845,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
       PM_STAMP(5);
       __builtin_amdgcn_s_barrier();  // opens M_t
       PM_STAMP(6);
-      if constexpr (DM) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < NTL; ++i)
-#pragma unroll
-          for (int j = 0; j < MT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[0][i].h, fx[0][j].h, acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + DP < nk) issue(t + DP);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < NTL; ++i)
-#pragma unroll
-          for (int j = 0; j < MT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[1][i].h, fx[1][j].h, acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      } else {
-        mma_all(fw, fx);
-      }
+      mma_all(fw, fx);
 #ifdef PM_GEMM_STAMP
       PM_STAMP(7);
 #pragma unroll
@@ -1102,8 +1076,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
 #endif
 }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, bool DM = false, int NW = 8,
-          bool SWP = false>
+template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, int NW = 8, bool SWP = false>
 int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   a.tiles_m = (a.M + BM_ - 1) / BM_;
   a.tiles_n = (a.N + BN_ - 1) / BN_;
@@ -1112,11 +1085,11 @@ int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   const size_t lds = ring > stage ? ring : stage;
   const dim3 grid(a.tiles_m * a.tiles_n), block(NW * 64);
   if (wk) {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP, false, DM, NW, SWP>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP, false, NW, SWP>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP, false, DM, NW, SWP>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP, false, NW, SWP>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   }
@@ -1130,7 +1103,7 @@ int launch_v3_wgrad(GemmArgs a, hipStream_t s) {
   a.tiles_n = (a.N + BN_ - 1) / BN_;
   constexpr int ring = 4 * (BM_ + BN_) * 64;
   const dim3 grid(a.tiles_m * a.tiles_n, a.split_k), block(512);
-  auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, 4, 2, true, !SWP, true, false, 8, SWP>;
+  auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, 4, 2, true, !SWP, true, 8, SWP>;
   PM_ALLOW_LDS(kern, ring);
   hipLaunchKernelGGL(kern, grid, block, ring, s, a);
   return pm_check_launch();
@@ -1260,9 +1233,8 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
   }
   // large-tile ring kernel: bf16, X k-normal (forward and dgrad GEMMs), big M
   if (in_dtype == PM_BF16 && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (g_force_cfg & 63) != 1) {
-    // Tile / pipeline choice, tuned on the ViT-B/16 shapes at M = 12608 (scratch/bench_gemm2.py; all land within
-    // ~10 % of each other -- see DESIGN.md): cfg 3 = 256x256 4-stage ring, LDS-staged epilogue; 6 = same with the
-    // direct register epilogue; 4 = 128x256 3-stage, 2 blocks/CU; 7 = 128x256 2-stage, 3 blocks/CU.
+    // Tile / pipeline choice, tuned on the ViT-B/16 shapes at M = 12608 (scratch/bench_gemm6.py).
+    // pm_debug_gemm_config(cfg) forces one of the variants below (0 = the heuristics).
     int cfg = g_force_cfg & 63;
     if (cfg == 0) {
       // 256x256 ping-pong everywhere; LDS-staged epilogue for the wide act-typed outputs (qkv, fc1+GELU: whole
@@ -1286,32 +1258,16 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
       }
     }
     switch (cfg) {
-      case 2: return launch_v3<256, 128, 4, 2, 4, 2, false>(a, b_kmajor, s);
-      case 4: return launch_v3<128, 256, 2, 4, 3, 4, true>(a, b_kmajor, s);
-      case 5: return launch_v3<256, 128, 4, 2, 3, 4, true>(a, b_kmajor, s);
-      case 6: return launch_v3<256, 256, 2, 4, 4, 2, true>(a, b_kmajor, s);
-      case 7: return launch_v3<128, 256, 2, 4, 2, 4, true>(a, b_kmajor, s);
-      case 8: return launch_v3<256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);  // ping-pong halves
-      case 9: return launch_v3<256, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);
-      case 10: return launch_v3<192, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);  // 192-row tiles: finer M granularity
-      case 11: return launch_v3<256, 256, 2, 4, 4, 2, false, true, true>(a, b_kmajor, s);  // DMA refill inside the MFMA phase
-      case 12: return launch_v3<256, 256, 2, 4, 4, 2, true, true, true>(a, b_kmajor, s);
-      case 13: return launch_v3<192, 256, 2, 4, 4, 2, true, true, true>(a, b_kmajor, s);
-      // 4-wave blocks, two (or three) independent blocks per CU: one block's epilogue / prologue runs under the other's k-loop
-      case 16: return launch_v3<128, 256, 2, 2, 3, 2, true, false, false, 4>(a, b_kmajor, s);
-      case 17: return launch_v3<128, 256, 2, 2, 3, 2, false, false, false, 4>(a, b_kmajor, s);
-      case 18: return launch_v3<256, 128, 2, 2, 3, 2, true, false, false, 4>(a, b_kmajor, s);
-      case 19: return launch_v3<256, 128, 2, 2, 3, 2, false, false, false, 4>(a, b_kmajor, s);
-      case 20: return launch_v3<128, 128, 2, 2, 3, 3, true, false, false, 4>(a, b_kmajor, s);
-      case 21: return launch_v3<128, 128, 2, 2, 4, 2, true, false, false, 4>(a, b_kmajor, s);
+      case 6: return launch_v3<256, 256, 2, 4, 4, 2, true>(a, b_kmajor, s);          // plain ring loop, register epilogue
+      case 8: return launch_v3<256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);   // ping-pong, LDS-staged epilogue
+      case 9: return launch_v3<256, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);    // ping-pong, register epilogue
+      case 10: return launch_v3<192, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);   // 192-row tiles: finer M granularity
       // software-pipelined loop (fragment reads and DMA issue between the wave's own MFMAs)
-      case 27: return launch_v3<128, 256, 2, 2, 3, 2, true, false, false, 4, true>(a, b_kmajor, s);   // two 4-wave blocks / CU
-      case 28: return launch_v3<128, 256, 2, 2, 3, 2, false, false, false, 4, true>(a, b_kmajor, s);
-      case 29: return launch_v3<256, 128, 2, 2, 3, 2, true, false, false, 4, true>(a, b_kmajor, s);
-      case 30: return launch_v3<256, 128, 2, 2, 3, 2, false, false, false, 4, true>(a, b_kmajor, s);
-      case 24: return launch_v3<256, 256, 2, 4, 4, 2, false, false, false, 8, true>(a, b_kmajor, s);
-      case 25: return launch_v3<256, 256, 2, 4, 4, 2, true, false, false, 8, true>(a, b_kmajor, s);
-      case 26: return launch_v3<192, 256, 2, 4, 4, 2, true, false, false, 8, true>(a, b_kmajor, s);
+      case 24: return launch_v3<256, 256, 2, 4, 4, 2, false, false, 8, true>(a, b_kmajor, s);
+      case 25: return launch_v3<256, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);
+      case 26: return launch_v3<192, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);
+      // two 4-wave blocks per CU (128x256 tiles, 3-slot ring): measured slower everywhere, kept for the record
+      case 27: return launch_v3<128, 256, 2, 2, 3, 2, false, false, 4, true>(a, b_kmajor, s);
       default: return launch_v3<256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
     }
   }
