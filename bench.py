@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-stats", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--input", choices=["resident", "host"], default="resident",
+                    help="resident (the contract: batch already in HBM) or host: uint8 HWC frames in pinned host memory, "
+                         "copied and normalised on a side stream each step (PCIe-inclusive rate, DESIGN.md)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step as one hipGraph (auto = off: eager launch keeps up and overlaps the two streams better)")
     return ap.parse_args()
@@ -82,7 +85,7 @@ def make_batch(workload, batch, device, rank):
 def make_step(workload, ddp, opt, imgs, labels):
     pos_weight = torch.tensor(1.0, device=imgs.device)
     if workload == "cls":
-        def step():
+        def step(imgs=imgs, labels=labels):
             opt.zero_grad(set_to_none=True)
             logits = ddp(imgs)
             z = logits[:, 1] - logits[:, 0]                       # tc.py:3347-3359
@@ -91,7 +94,7 @@ def make_step(workload, ddp, opt, imgs, labels):
             opt.step()
             return loss
     else:
-        def step():
+        def step(imgs=imgs, labels=labels):
             opt.zero_grad(set_to_none=True)
             loss, _, _ = ddp(imgs, mask_ratio=0.75)
             loss.backward()
@@ -200,15 +203,33 @@ def main():
     else:
         step = eager_step
 
-    for _ in range(args.warmup):
-        step()
+    def host_feed(n):
+        # uint8 HWC frames + labels in pinned host memory -> DevicePrefetcher (H2D + flips + ToTensor + Normalize)
+        from ssl4polyp_amd.data import DevicePrefetcher
+        g = torch.Generator().manual_seed(1234 + rank)
+        pool = [(torch.randint(0, 256, (batch, 224, 224, 3), dtype=torch.uint8, generator=g).pin_memory(),
+                 (torch.rand(batch, generator=g) < 0.5).long().pin_memory()) for _ in range(4)]
+        return DevicePrefetcher([pool[i % 4] for i in range(n)], device, flip_p=0.5, generator=g)
+
+    if args.input == "host":
+        if use_graph:
+            sys.exit("--input host feeds a new batch every step: use eager launch")
+        for im, lb in host_feed(args.warmup):
+            step(im, lb)
+    else:
+        for _ in range(args.warmup):
+            step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    if args.input == "host":
+        for im, lb in host_feed(args.steps):
+            loss = step(im, lb)
+    else:
+        for _ in range(args.steps):
+            loss = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -240,7 +261,8 @@ def main():
             "metric": "training-step images/sec/node, ViT-B/16 224^2 (" + ("cls fine-tune" if args.workload == "cls" else "MAE pre-train") + ")",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic" if args.input == "resident" else "synthetic uint8 frames in pinned host memory (PCIe-inclusive)",
             "config": {"workload": ("ViT-B/16 classification fine-tune" if args.workload == "cls" else
                                     "MAE pre-train ViT-B/16 mask 0.75") + f", bs={batch}/GPU, 224^2, AdamW, random init",
                        "global_batch": batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),

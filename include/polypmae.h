@@ -149,6 +149,15 @@ int pm_mae_loss_bwd(const float* imgs, const float* pred, long ldp, int has_cls_
 /* f32 -> act cast (weight shadow copies for the bf16 MFMA path). */
 int pm_cast(const float* src, void* dst, int dst_dtype, long n, void* stream);
 
+/* Device-side tail of the input pipeline -- replaces torchvision `ToTensor()` + `Normalize(mean, std)`
+ * and the two random flips of the reference's transform (classification/data/transforms.py:225-253) on frames that
+ * arrive as decoded uint8: src u8 [B][H][W][3] (HWC, what PIL / numpy hold), dst f32 [B][3][H][W].
+ *   dst = (float(src) / 255 - mean[c]) / std[c]   (same operations, same order, IEEE f32: bit-exact with torchvision)
+ * flip_flags: u8 [B] or NULL; bit 0 = horizontal flip, bit 1 = vertical flip of that sample.  W % 4 == 0.
+ * A uint8 batch is a quarter of the f32 batch on PCIe (9.6 MB instead of 38.5 MB at B = 64). */
+int pm_preprocess_u8(const unsigned char* src, const unsigned char* flip_flags, float* dst, int B, int H, int W,
+                     float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
+
 /* Classifier head on the cls rows (models.py:209,216-221 + tc.py:3347-3374): final LayerNorm of row 0 of each
  * sample, Linear(D -> n_class) in f32.  x f32 [B, N, D]. */
 int pm_cls_head_fwd(const float* x, int N, const float* gamma, const float* beta, const float* W, const float* bias,

@@ -38,6 +38,7 @@ SIGNATURES = {
     "pm_mae_loss_finish": [P, P, L, P, P, P],
     "pm_mae_loss_bwd": [P, P, L, I, P, P, P, P, I, I, I, I, I, I, P],
     "pm_cast": [P, P, I, L, P],
+    "pm_preprocess_u8": [P, P, P, I, I, I, F, F, F, F, F, F, P],
     "pm_cls_head_fwd": [P, I, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "pm_cls_head_bwd": [P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, I, I, I, P],
     "pm_adamw": [P, P, P, P, P, I, L, F, F, F, F, F, I, F, P],

@@ -133,6 +133,41 @@ __global__ __launch_bounds__(256) void cls_grad_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// input tail: uint8 HWC frames -> normalised f32 NCHW  (torchvision ToTensor + Normalize, optional flips)
+// ---------------------------------------------------------------------------------------------
+// One thread = 4 consecutive output pixels of one row: 12 source bytes -> one f32x4 per channel plane.
+// Arithmetic and its order are torchvision's: v = float(u8) / 255 ; (v - mean) / std, IEEE f32 division.
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ src,
+                                                            const unsigned char* __restrict__ flags, float* __restrict__ dst,
+                                                            int B, int H, int W, f32x4 mean, f32x4 stdv) {
+  const int w4 = W >> 2;
+  const long total = (long)B * H * w4;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int xq = id % w4;
+    const int y = (id / w4) % H;
+    const int b = id / ((long)w4 * H);
+    const int f = flags ? flags[b] : 0;
+    const int sy = (f & 2) ? H - 1 - y : y;
+    const unsigned char* row = src + ((long)b * H + sy) * W * 3;
+    float px[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int x = xq * 4 + i;
+      const int sx = (f & 1) ? W - 1 - x : x;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) px[i][c] = (float)row[sx * 3 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = __fdiv_rn(__fdiv_rn(px[i][c], 255.0f) - mean[c], stdv[c]);
+      *reinterpret_cast<f32x4*>(dst + (((long)b * 3 + c) * H + y) * W + xq * 4) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // cast
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -450,6 +485,20 @@ extern "C" int pm_assemble_tokens_bwd(const float* dx, const int* ids_keep, void
   if (dcls)
     hipLaunchKernelGGL(cls_grad_kernel, dim3((D + 255) / 256), dim3(256), 0, pm_stream(stream), dx, dcls, dpos, B,
                        (long)(keep + 1) * D, D);
+  return pm_check_launch();
+}
+
+extern "C" int pm_preprocess_u8(const unsigned char* src, const unsigned char* flip_flags, float* dst, int B, int H, int W,
+                                float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b,
+                                void* stream) {
+  if (!src || !dst) return PM_EINVAL;
+  if (B <= 0 || H <= 0 || W <= 0 || (W & 3)) return PM_ESHAPE;
+  if (((uintptr_t)dst & 15)) return PM_EALIGN;
+  if (!(std_r > 0.f) || !(std_g > 0.f) || !(std_b > 0.f)) return PM_EINVAL;
+  const long total = (long)B * H * (W >> 2);
+  const dim3 grid(cap_grid(total, 256, 8192));
+  hipLaunchKernelGGL(preprocess_u8_kernel, grid, dim3(256), 0, pm_stream(stream), src, flip_flags, dst, B, H, W,
+                     f32x4{mean_r, mean_g, mean_b, 0.f}, f32x4{std_r, std_g, std_b, 1.f});
   return pm_check_launch();
 }
 
