@@ -202,17 +202,48 @@ def train_epoch_cls(model, train_loader: Iterable, optimizer, device, pos_weight
     return stats
 
 
+def class_probabilities(logits: torch.Tensor) -> torch.Tensor:
+    """tc.py:4700-4730: binary packs (n_class = 2) score with sigmoid(l1 - l0), multi-class with softmax -- computed on
+    the device the logits live on.  Returns [B] (binary: P(class 1)) or [B, n_class]."""
+    logits = logits.float()
+    if logits.shape[-1] == 2:
+        return torch.sigmoid(logits[:, 1] - logits[:, 0])
+    return torch.softmax(logits, dim=-1)
+
+
 @torch.no_grad()
-def evaluate_cls(model, loader: Iterable, device, max_batches: Optional[int] = None):
-    """tc.py:4652-4812 forward part: logits and targets gathered on the host (metrics stay in the reference's code)."""
+def evaluate_cls(model, loader: Iterable, device, max_batches: Optional[int] = None, shard: Optional[bool] = None,
+                 return_probs: bool = False):
+    """tc.py:4652-4812 forward part: forward-only kernels in eval mode; logits (and optionally on-device probabilities)
+    and targets gathered on the host (metrics stay in the reference's code).
+    shard (default: whenever torch.distributed is initialised with world > 1): every rank walks the SAME loader and
+    evaluates batches i with i % world == rank; the pieces are all-gathered and returned in loader order on every rank
+    -- the reference validates on rank 0 only while the other GPUs idle (tc.py:6660-6728)."""
     model.eval()
-    logits, targets = [], []
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    if shard is None:
+        shard = world > 1
+    if not shard:
+        world, rank = 1, 0
+    mine = []
     for it, batch in enumerate(loader):
         if max_batches is not None and it >= max_batches:
             break
-        logits.append(model(batch[0].to(device, non_blocking=True)).float().cpu())
-        targets.append(batch[1].cpu())
-    return torch.cat(logits), torch.cat(targets)
+        if it % world != rank:
+            continue
+        lg = model(batch[0].to(device, non_blocking=True)).float()
+        pr = class_probabilities(lg) if return_probs else None
+        mine.append((it, lg.cpu(), batch[1].cpu(), pr.cpu() if pr is not None else None))
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        mine = sorted((x for p in parts for x in p), key=lambda x: x[0])
+    logits = torch.cat([x[1] for x in mine])
+    targets = torch.cat([x[2] for x in mine])
+    if return_probs:
+        return logits, targets, torch.cat([x[3] for x in mine])
+    return logits, targets
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -80,3 +80,53 @@ def test_bucketed_allreduce_schedule_gloo(bucket_mb, min_launches):
         assert covered, f"rank {rank}: buckets do not tile the flat gradient range exactly once"
         assert untouched
         assert n >= min_launches
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ssl4polyp_amd import train as T
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(12, 2))  # same weights on every rank (seeded)
+        g = torch.Generator().manual_seed(5)
+        loader = [(torch.randn(3 + (i % 2), 3, 2, 2, generator=g), torch.arange(3 + (i % 2)) + 100 * i) for i in range(5)]
+        seen = []
+        fwd = model.forward
+        model.forward = lambda x: (seen.append(x.shape[0]), fwd(x))[1]
+        lg, tg, pr = T.evaluate_cls(model, loader, "cpu", return_probs=True)
+        q.put((rank, lg.numpy(), tg.numpy(), pr.numpy(), len(seen)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_evaluation_gloo():
+    """evaluate_cls under world 2: each rank runs only its share of the batches, all ranks return the full result in
+    loader order, equal to the single-process evaluation."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r = q.get(timeout=120)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from ssl4polyp_amd import train as T
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(12, 2))
+    g = torch.Generator().manual_seed(5)
+    loader = [(torch.randn(3 + (i % 2), 3, 2, 2, generator=g), torch.arange(3 + (i % 2)) + 100 * i) for i in range(5)]
+    lg, tg, pr = T.evaluate_cls(model, loader, "cpu", return_probs=True)
+    assert torch.allclose(pr, torch.sigmoid(lg[:, 1] - lg[:, 0]))
+    for rank in (0, 1):
+        rl, rt, rp, n_fwd = res[rank]
+        assert n_fwd == (3 if rank == 0 else 2)  # batches 0,2,4 / 1,3
+        assert torch.equal(torch.from_numpy(rl), lg) and torch.equal(torch.from_numpy(rt), tg)
+        assert torch.equal(torch.from_numpy(rp), pr)
+    # multi-class: softmax
+    assert torch.allclose(T.class_probabilities(torch.tensor([[1.0, 2.0, 3.0]])).sum(), torch.tensor(1.0))
