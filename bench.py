@@ -28,6 +28,8 @@ sys.path.insert(0, REPO)
 # algorithmic GFLOP per image per training step (contractions only, step = 3 x forward)
 GFLOP_PER_IMG = {"cls": 105.38, "mae": 58.16}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense bf16 MFMA / f32 MFMA
+PEAK_HBM_GBPS = 8000.0                         # MI355X_MICROARCH.md: HBM3E
+HBM_KERNELS = {}
 
 
 def parse():
@@ -116,14 +118,39 @@ def kernel_stats(model, step):
         e1.record()
         rec.append((("tn" if akm else "n") + ("n" if bkm else "t"), M, N, K, e0, e1))
 
-    k.gemm = timed
+    # the HBM-bound kernels of the path, timed the same way: algorithmic bytes / launch time against the HBM peak
+    hbm = []
+    orig_lnf, orig_lnb = k.layernorm_fwd, k.layernorm_bwd
+    act_b = 2 if model._rt.k.precision == "bf16" else 4
+
+    def ln_fwd(x, gamma, beta, y, mean, rstd, M, D):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); orig_lnf(x, gamma, beta, y, mean, rstd, M, D); e1.record()
+        hbm.append(("layernorm_fwd", M * D * (4 + act_b), e0, e1))
+
+    def ln_bwd(dy, x, gamma, mean, rstd, dres, dx, dx_act, dgamma, dbeta, dcolsum, M, D):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); orig_lnb(dy, x, gamma, mean, rstd, dres, dx, dx_act, dgamma, dbeta, dcolsum, M, D); e1.record()
+        hbm.append(("layernorm_bwd", M * D * (act_b + 4 + 4 + 4 + act_b), e0, e1))
+
+    k.gemm, k.layernorm_fwd, k.layernorm_bwd = timed, ln_fwd, ln_bwd
     try:
         for _ in range(3):
             rec.clear()
+            hbm.clear()
             step()
         torch.cuda.synchronize()
     finally:
-        k.gemm = orig
+        k.gemm, k.layernorm_fwd, k.layernorm_bwd = orig, orig_lnf, orig_lnb
+    hb = {}
+    for name, nbytes, e0, e1 in hbm:
+        d = hb.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += nbytes
+    global HBM_KERNELS
+    HBM_KERNELS = {n: {"launches": c, "avg_us": round(t / c * 1e6, 2), "GBps": round(b / t / 1e9, 1),
+                       "frac_of_hbm_peak": round(b / t / 1e9 / PEAK_HBM_GBPS, 3)} for n, (c, t, b) in hb.items()}
     by = {}
     for lay, M, N, K, e0, e1 in rec:
         d = by.setdefault(lay, [0, 0.0, 0.0])
@@ -255,7 +282,16 @@ def main():
             dom = max(ks.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])
             roof["kernel"] = {"name": f"gemm_kernel<{args.precision},{dom[0]}>", **dom[1],
                               "frac": round(dom[1]["tflops"] / peak, 4)}
+            try:  # PMC traffic of the dominant kernel, from the committed rocprofv3 --pmc passes (profiles/)
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
+                    t = json.load(fh).get(args.workload, {}).get(dom[0])
+                if t and args.precision == "bf16" and batch == 64:
+                    roof["traffic"] = {"MB_per_launch": t["MB_per_launch"], "algorithmic_MB_per_launch": t["algorithmic_MB_per_launch"],
+                                       "source": t["source"]}
+            except (OSError, ValueError):
+                pass
             roof["gemm_by_layout"] = ks
+            roof["hbm_kernels"] = HBM_KERNELS  # in-step (beside the weight-gradient stream), algorithmic bytes / time
             roof["gemm_share_of_step"] = round(gt / (dt / args.steps), 3)
         out = {
             "metric": "training-step images/sec/node, ViT-B/16 224^2 (" + ("cls fine-tune" if args.workload == "cls" else "MAE pre-train") + ")",
