@@ -30,6 +30,7 @@ GFLOP_PER_IMG = {"cls": 105.38, "mae": 58.16}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense bf16 MFMA / f32 MFMA
 PEAK_HBM_GBPS = 8000.0                         # MI355X_MICROARCH.md: HBM3E
 HBM_KERNELS = {}
+OVERLAP_ADAMW = os.environ.get("PM_OVERLAP_ADAMW", "1") != "0"  # A/B switch: AdamW beside the next forward
 
 
 def parse():
@@ -67,11 +68,11 @@ def build(workload, precision, device, world, batch):
         hid = {id(p) for p in head}
         groups = [{"params": head, "name": "head"},
                   {"params": [p for p in model.parameters() if id(p) not in hid and p.requires_grad], "name": "backbone"}]
-        opt = FusedAdamW(model, groups, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.05)
+        opt = FusedAdamW(model, groups, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.05, overlap_forward=OVERLAP_ADAMW)
     else:
         # main_pretrain.py:201-218: lr = blr * eff_batch / 256, betas (0.9, 0.95), no decay on 1-D params
         lr = 1e-3 * batch * world / 256
-        opt = FusedAdamW(model, add_weight_decay(model, 0.05), lr=lr, betas=(0.9, 0.95))
+        opt = FusedAdamW(model, add_weight_decay(model, 0.05), lr=lr, betas=(0.9, 0.95), overlap_forward=OVERLAP_ADAMW)
     opt.grad_sync = ddp.sync
     opt.grad_scale = 1.0 / world
     return model, ddp, opt

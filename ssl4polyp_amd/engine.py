@@ -219,12 +219,16 @@ class BlockStack:
     def __init__(self, k: Kernels, g: StackGeom):
         self.k, self.g = k, g
 
-    def forward(self, ws: StackWorkspace, x_in: torch.Tensor, W: Sequence[Dict[str, torch.Tensor]]) -> torch.Tensor:
-        """x_in f32 [M, D]; W[i] maps BLOCK_PARAM_NAMES -> tensors (matrices act-typed, vectors f32)."""
+    def forward(self, ws: StackWorkspace, x_in: torch.Tensor, W: Sequence[Dict[str, torch.Tensor]],
+                before_block: Optional[Callable[[int], None]] = None) -> torch.Tensor:
+        """x_in f32 [M, D]; W[i] maps BLOCK_PARAM_NAMES -> tensors (matrices act-typed, vectors f32).
+        before_block(i) runs before block i's first kernel (gate on a pending optimizer update of its weights)."""
         k, g = self.k, self.g
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
         x = x_in
         for i in range(g.depth):
+            if before_block is not None:
+                before_block(i)
             bw, p = ws.block(i), W[i]
             k.layernorm_fwd(x, p["norm1.weight"], p["norm1.bias"], bw.ln1, bw.mean1, bw.rstd1, M, D)
             k.linear_fwd(bw.ln1, p["attn.qkv.weight"], p["attn.qkv.bias"], bw.qkv, M, 3 * D, D)

@@ -103,6 +103,29 @@ class _Runtime:
         self.grad_sync = None  # parallel.GradSync, set by DataParallel wrapper
         self._wcache: Dict[str, tuple] = {}
         self.eps = 1e-6
+        # optimizer updates still running on the side stream (FusedAdamW(overlap_forward=True)): (region, lo, hi, event)
+        # in launch order; the forward waits for a block's range right before it reads the block's weights
+        self.pending_updates: List[tuple] = []
+
+    def wait_updates(self, mat_through: Optional[int] = None) -> None:
+        """Make the current stream wait for pending optimizer updates: all of them (default), or every `vec` update
+        and the `mat` updates starting below offset `mat_through`.  The updates run in order on one stream, so waiting
+        for the last needed one covers everything launched before it."""
+        if not self.pending_updates:
+            return
+        last = -1
+        for j, (r, lo, hi, ev) in enumerate(self.pending_updates):
+            if mat_through is None or r == "vec" or lo < mat_through:
+                last = j
+        if last >= 0:
+            torch.cuda.current_stream().wait_event(self.pending_updates[last][3])
+            del self.pending_updates[:last + 1]
+
+    def block_end(self, prefix: str, i: int) -> int:
+        """End offset (in `mat`) of block i's matrices: what `wait_updates` needs before the block runs."""
+        f = self.flat
+        j = f.index[f"{prefix}{i}.mlp.fc2.weight"]
+        return f.offset[j] + f.numel[j]
 
     def ensure(self, device: torch.device) -> None:
         if device.type != "cuda":
@@ -117,8 +140,12 @@ class _Runtime:
             self.pool.clear()
             self._wcache = {}
         if self.flat.shadow_stale():
+            self.wait_updates()
             self.k.cast(self.flat.P["mat"], self.flat.S)
             self.flat.mark_shadow_fresh()
+        if self.pending_updates:  # vectors, tokens and everything in front of the first block (patch / decoder embed)
+            f = self.flat
+            self.wait_updates(mat_through=f.offset[f.index["blocks.0.attn.qkv.weight"]])
 
     # weights / grads of one block stack as dicts of persistent views
     def stack_weights(self, prefix: str, depth: int):
@@ -147,6 +174,13 @@ class _Runtime:
 
     def put_ws(self, geom: StackGeom, ws: StackWorkspace) -> None:
         self.pool.setdefault((geom.dim, geom.depth, ws.B, ws.N, ws.training), []).append(ws)
+
+
+def _update_gate(rt: _Runtime, prefix: str):
+    """before_block hook of BlockStack.forward: wait for the optimizer update of block i's weights (if one is pending)."""
+    if not rt.pending_updates:
+        return None
+    return lambda i: rt.wait_updates(mat_through=rt.block_end(prefix, i))
 
 
 def _plan_grads(rt: _Runtime, names: List[str], needs: List[bool]):
@@ -216,7 +250,8 @@ class _VitClsFn(torch.autograd.Function):
         cols, x0 = _EncoderFrontMixin.front_fwd(rt, imgs, None, L)
         ws = rt.get_ws(g, B, N, training)
         W, _ = rt.stack_weights("blocks.", g.depth)
-        x = BlockStack(k, g).forward(ws, x0, W)
+        x = BlockStack(k, g).forward(ws, x0, W, before_block=_update_gate(rt, "blocks."))
+        rt.wait_updates()  # norm / lin_head and anything else still pending
         n_class = mod.lin_head.weight.shape[0]
         dev = imgs.device
         xn = torch.empty(B, D, dtype=torch.float32, device=dev)
@@ -309,7 +344,8 @@ class _MaeFn(torch.autograd.Function):
         cols, x0 = _EncoderFrontMixin.front_fwd(rt, imgs, ids_keep, keep)
         ws_e = rt.get_ws(ge, B, keep + 1, training)
         We, _ = rt.stack_weights("blocks.", ge.depth)
-        xe = BlockStack(k, ge).forward(ws_e, x0, We)
+        xe = BlockStack(k, ge).forward(ws_e, x0, We, before_block=_update_gate(rt, "blocks."))
+        rt.wait_updates()  # the decoder side is short: take the rest at once
         Me, Md = B * (keep + 1), B * (L + 1)
         latent = torch.empty(Me, De, dtype=k.act_dtype, device=dev)
         mean_e, rstd_e = torch.empty(Me, dtype=f32, device=dev), torch.empty(Me, dtype=f32, device=dev)
@@ -433,6 +469,10 @@ class _MaeFn(torch.autograd.Function):
 class MaskedAutoencoderViT(nn.Module):
     """Masked Autoencoder with VisionTransformer backbone (models_mae.py:22-220), HIP-executed."""
 
+    def state_dict(self, *args, **kwargs):
+        self._rt.wait_updates()  # an overlapped optimizer update may still be writing the parameters
+        return super().state_dict(*args, **kwargs)
+
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16,
                  decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4.0, norm_layer=nn.LayerNorm,
                  norm_pix_loss=False, precision: Optional[str] = None):
@@ -543,6 +583,10 @@ mae_vit_huge_patch14 = mae_vit_huge_patch14_dec512d8b
 
 
 class _ClassifierBase(nn.Module):
+    def state_dict(self, *args, **kwargs):
+        self._rt.wait_updates()  # an overlapped optimizer update may still be writing the parameters
+        return super().state_dict(*args, **kwargs)
+
     def _classify(self, imgs):
         if self.dense:
             raise NotImplementedError("dense (DPT decoder) mode is dead code on the reference's path (every caller "

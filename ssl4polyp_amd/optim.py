@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Dict, Iterable, List, Optional
 
+import contextlib
+
 import torch
 
 from . import _lib
@@ -32,10 +34,16 @@ def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, model, params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, model, params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 overlap_forward: bool = False):
         """`model`: an ssl4polyp_amd module (owns the flat storage).  `params`: iterable of parameters or of
-        torch-style param-group dicts (default: all parameters of the model)."""
+        torch-style param-group dicts (default: all parameters of the model).
+        overlap_forward: run the update on the engine's side stream, block by block in forward order, and let the next
+        forward wait per block (the update is HBM-bound, the forward GEMMs MFMA-bound: ~0.5 ms of the step hides).
+        The model's forward / state_dict and this optimizer's state_dict / grad_stats wait for the update by
+        themselves; code that reads parameter tensors directly right after step() must call `sync()` first."""
         self._rt = model._rt
+        self.overlap_forward = bool(overlap_forward)
         if params is None:
             params = list(model.parameters())
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -119,27 +127,62 @@ class FusedAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         f = self._ensure_state()
+        rt = self._rt
+        rt.wait_updates()  # a previous overlapped update (reads the hyper records and the gradients)
         if self.grad_sync is not None:
             self.grad_sync.wait()
         capturing = f.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
         if not capturing or getattr(self, "_hyper", None) is None:
             self.sync_hyper()
         lib = self._rt.k.lib
-        _lib.check(lib.pm_adamw_tick(_ptr(self._hyper), len(self.param_groups), _stream()), "pm_adamw_tick")
+        overlap = self.overlap_forward and not capturing and f.device.type == "cuda"
+        work = []  # (group index, region, lo, hi)
         for gi, group in enumerate(self.param_groups):
             group["step"] = int(group.get("step", 0)) + 1  # host mirror (the device record is authoritative)
-            hyper = self._hyper[gi]
             for r, lo, hi in self._segments(f, group):
+                work.append((gi, r, lo, hi))
+        if overlap:
+            # forward order: vectors first, then the matrices by offset, cut at the block boundaries so that the next
+            # forward can start on block 0 while the later blocks are still being updated
+            cuts = sorted(f.offset[i] for i, n in enumerate(f.names) if n.endswith("attn.qkv.weight"))
+            split = []
+            for gi, r, lo, hi in work:
+                if r != "mat":
+                    split.append((gi, r, lo, hi))
+                    continue
+                pts = [lo] + [c for c in cuts if lo < c < hi] + [hi]
+                split += [(gi, r, a, b) for a, b in zip(pts[:-1], pts[1:])]
+            work = sorted(split, key=lambda w: (w[1] != "vec", w[2]))
+            main = torch.cuda.current_stream(f.device)
+            side = rt.k.side_stream(f.device)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            stream_ctx = torch.cuda.stream(side)
+        else:
+            stream_ctx = contextlib.nullcontext()
+        with stream_ctx:
+            _lib.check(lib.pm_adamw_tick(_ptr(self._hyper), len(self.param_groups), _stream()), "pm_adamw_tick")
+            for gi, r, lo, hi in work:
                 shadow = f.S[lo:hi] if (r == "mat" and f.S is not None) else None
                 _lib.check(lib.pm_adamw_dev(_ptr(f.P[r][lo:hi]), _ptr(f.G[r][lo:hi]), _ptr(self._M[r][lo:hi]),
                                             _ptr(self._V[r][lo:hi]), _ptr(shadow),
                                             _lib.dtype_code(shadow.dtype) if shadow is not None else 0, hi - lo,
-                                            _ptr(hyper), _stream()), "pm_adamw_dev")
+                                            _ptr(self._hyper[gi]), _stream()), "pm_adamw_dev")
+                if overlap:
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    rt.pending_updates.append((r, lo, hi, done))
         return loss
+
+    def sync(self) -> None:
+        """Make the current stream wait for an overlapped update (no-op otherwise)."""
+        self._rt.wait_updates()
 
     def grad_stats(self) -> torch.Tensor:
         """Device tensor [sum(g^2), #NaN, #Inf] over every gradient of every group (no host sync)."""
         f = self._ensure_state()
+        self._rt.wait_updates()
         out = torch.zeros(3, dtype=torch.float32, device=f.device)
         lib = self._rt.k.lib
         for group in self.param_groups:
@@ -149,6 +192,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     # -- torch.optim.AdamW-compatible (de)serialisation --------------------------------------------
     def state_dict(self):
+        self._rt.wait_updates()
         f = self._rt.flat
         idx = {id(p): i for i, p in enumerate(f.params)} if f is not None else {}
         state, groups, k = {}, [], 0
@@ -170,6 +214,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, sd):
         f = self._ensure_state()
+        self._rt.wait_updates()
         idx = {id(p): i for i, p in enumerate(f.params)}
         for group, saved in zip(self.param_groups, sd["param_groups"]):
             for kk, v in saved.items():
