@@ -68,7 +68,7 @@ def run(args, data_loader=None):
     eff = args.batch_size * args.accum_iter * world
     if args.lr is None:
         args.lr = args.blr * eff / 256
-    opt = FusedAdamW(model, add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95))
+    opt = FusedAdamW(model, add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95), overlap_forward=True)
     opt.grad_sync = ddp.sync
     opt.grad_scale = 1.0 / world
     if args.resume:  # (DataParallel() above already bound the parameters to the flat device storage)
