@@ -1280,11 +1280,11 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
   // large-K wgrad on the ping-pong ring kernel: 256x128 tiles, split so that tiles x splits ~ one block per CU
   if (splittable && in_dtype == PM_BF16 && a_kmajor && b_kmajor && (K % V3_KE) == 0 && K >= 2048 && M >= 256 && N >= 128 &&
       (g_force_cfg & 63) != 1) {
-    // 256x256 tiles (twice the MFMAs per barrier) once there are enough of them to split K over the chip
-    // (qkv / fc1 / fc2 gradients: 27-36 tiles, 74 us vs 83); 256x128 for the small 768x768 projection gradient.
+    // 256x256 tiles (twice the MFMAs per barrier) from 2x2 tiles up: ViT-B qkv / fc1 / fc2 gradients 74 us vs 83 with
+    // 256x128; the MAE decoder's 512-wide gradients (K = 50 432 tokens) +2.8 % step rate; neutral for 768x768.
     // Tuning hook bits 6-7: 1 = force 256x128, 2 = force 256x256, 3 = software-pipelined 256x256 (slower: tr reads).
     int wv = (g_force_cfg >> 6) & 3;
-    if (wv == 0) wv = ((M + 255) / 256) * ((N + 255) / 256) >= 24 ? 2 : 1;
+    if (wv == 0) wv = ((M + 255) / 256) * ((N + 255) / 256) >= 4 ? 2 : 1;
     const int bn3 = wv >= 2 ? 256 : 128;
     const int t3 = ((M + 255) / 256) * ((N + bn3 - 1) / bn3);
     const int nk3 = K / V3_KE;

@@ -64,7 +64,7 @@ class Kernels:
                                              _ptr(dgamma), _ptr(dbeta), _ptr(dcolsum), M, D, _ptr(ws), ws.numel(), _stream()),
                    "pm_layernorm_bwd")
 
-    WGRAD_BLOCKS = 128
+    WGRAD_BLOCKS = int(os.environ.get("PM_WGRAD_BLOCKS", "128"))
     # fc1.bias gradient inside the dGELU dgrad epilogue (pm_gemm_colsum) instead of a column-sum kernel on the side
     # stream.  Off: the HBM-bound column sum overlaps the MFMA-bound GEMMs for free, while the fused reduction
     # lengthens the dgrad chain (measured -2.5 % step rate when fused).
