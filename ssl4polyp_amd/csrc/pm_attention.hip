@@ -172,27 +172,34 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_fwd_kernel(const T
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) s = mfma16B<T>(frag_rows<T, DH>(imgK, kt * 32, kk, lane), fq[kk], s);
       float tm = -INFINITY;
+      if (kt == NT - 1) {  // only the last key tile holds padded keys (zero rows of the K image): mask them out
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + acc_row(r, hh);
-        s[r] = key < N ? s[r] : -INFINITY;
-        tm = fmaxf(tm, s[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + acc_row(r, hh);
+          s[r] = key < N ? s[r] : -INFINITY;
+        }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tm = fmaxf(tm, s[r]);
       tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
       const float mn = fmaxf(m, tm);  // finite from the first tile on (key 0 is always valid)
       const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+      const float mnc = mn * c;
       float ts = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = __builtin_amdgcn_exp2f((s[r] - mn) * c);
+        s[r] = __builtin_amdgcn_exp2f(s[r] * c - mnc);
         ts += s[r];
       }
       l = l * alpha + ts;
+      const bool moved = __builtin_amdgcn_ballot_w64(mn != m) != 0;  // after the first tiles the running max rarely moves
       m = mn;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
+        if (moved) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
         o[dt] = mma_imgT_acc<T, DH>(imgV, kt * 32, dt * 32, s, o[dt], lane);
       }
     }
@@ -252,6 +259,7 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const
     const long sidx = ((long)b * H + h) * N + q;
     if (qv && hh == 0) delta[sidx] = dl;
     const float l2 = qv ? lse[sidx] * kLog2e : 0.f;
+    const float dls = dl * scale;
     f32x16 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
@@ -263,12 +271,10 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const
         s = mfma16B<T>(frag_rows<T, DH>(imgK, kt * 32, kk, lane), fq[kk], s);
         dp = mfma16B<T>(frag_rows<T, DH>(imgV, kt * 32, kk, lane), fdo[kk], dp);
       }
+      // no masking: a padded key has a zero K row, so its (finite) dS is multiplied by zeros in the dQ product
+      // below; a padded query's lane is never stored
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + acc_row(r, hh);
-        const float p = (key < N && qv) ? __builtin_amdgcn_exp2f(s[r] * c - l2) : 0.f;
-        s[r] = p * (dp[r] - dl) * scale;  // dS^T
-      }
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * c - l2) * (dp[r] * scale - dls);  // dS^T
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[dt] = mma_imgT_acc<T, DH>(imgK, kt * 32, dt * 32, s, dq[dt], lane);
     }
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(cons
   for (int i = tid; i < NT * 32; i += NW * 64) {
     const long sidx = ((long)b * H + h) * N + i;
     sl2[i] = i < N ? lse[sidx] * kLog2e : 0.f;
-    sdl[i] = i < N ? delta[sidx] : 0.f;
+    sdl[i] = i < N ? delta[sidx] * scale : 0.f;
   }
   __syncthreads();
   const float c = scale * kLog2e;
@@ -331,12 +337,20 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(cons
         s = mfma16B<T>(frag_rows<T, DH>(imgQ, qt * 32, kk, lane), fk[kk], s);
         dp = mfma16B<T>(frag_rows<T, DH>(imgDO, qt * 32, kk, lane), fv[kk], dp);
       }
+      // no masking: a padded query has zero Q and dO rows (and lse = delta = 0 in LDS), so its finite P / dS rows
+      // meet zeros in both products below; a padded key's lane is never stored.  sdl holds delta * scale.
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = qt * 32 + acc_row(r, hh);
-        const float p = (q < N && kv) ? __builtin_amdgcn_exp2f(s[r] * c - sl2[q]) : 0.f;
-        s[r] = p;                                // P
-        dp[r] = p * (dp[r] - sdl[q]) * scale;    // dS
+      for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are queries qt*32 + 8g + 4hh + 0..3: one 16-B LDS read each
+        const int q = qt * 32 + 8 * g + 4 * hh;
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl2 + q);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sdl + q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float p = __builtin_amdgcn_exp2f(s[r] * c - l4[e]);
+          s[r] = p;                                // P
+          dp[r] = p * (dp[r] * scale - d4[e]);     // dS
+        }
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
