@@ -263,7 +263,8 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const
     f32x16 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
-#pragma unroll 1
+    // dh = 32: two key tiles in flight per wave (the loop is a latency chain; registers allow it: 80 VGPRs)
+#pragma unroll (DH == 32 ? 2 : 1)
     for (int kt = 0; kt < NT; ++kt) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(cons
       dk[dt] = zero16();
       dv[dt] = zero16();
     }
-#pragma unroll 1
+#pragma unroll (DH == 32 ? 2 : 1)
     for (int qt = 0; qt < NT; ++qt) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
