@@ -18,6 +18,7 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
+import contextlib
 import os
 
 import torch
@@ -64,6 +65,7 @@ class Kernels:
                                              _ptr(dgamma), _ptr(dbeta), _ptr(dcolsum), M, D, _ptr(ws), ws.numel(), _stream()),
                    "pm_layernorm_bwd")
 
+    SPLIT_FORWARD = int(os.environ.get("PM_SPLIT_FWD", "2"))  # forward: this many sub-batches as concurrent chains (1 = off)
     WGRAD_BLOCKS = int(os.environ.get("PM_WGRAD_BLOCKS", "128"))
     # fc1.bias gradient inside the dGELU dgrad epilogue (pm_gemm_colsum) instead of a column-sum kernel on the side
     # stream.  Off: the HBM-bound column sum overlaps the MFMA-bound GEMMs for free, while the fused reduction
@@ -80,6 +82,15 @@ class Kernels:
             ws = torch.empty(1024 * 3 * 1024 * 4, dtype=torch.uint8, device=device)
             self._ws_ln = ws
         return ws
+
+    def aux_stream(self, device, j: int = 0):
+        pool = getattr(self, "_aux", None)
+        if pool is None or (pool and pool[0].device != device):
+            pool = []
+            self._aux = pool
+        while len(pool) <= j:
+            pool.append(torch.cuda.Stream(device=device))
+        return pool[j]
 
     def side_stream(self, device):
         st = getattr(self, "_side", None)
@@ -225,20 +236,55 @@ class BlockStack:
         before_block(i) runs before block i's first kernel (gate on a pending optimizer update of its weights)."""
         k, g = self.k, self.g
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
+        # The forward has no second stream of its own work to share the CUs with, so the batch is cut into two halves
+        # that run as independent chains on two streams: one half's GEMM tails / attention / LayerNorm fill the CUs
+        # the other half's kernels leave idle (every op is per token or per (sample, head), and the halves write
+        # disjoint row ranges of the same workspaces, so the backward sees one batch).
+        main = torch.cuda.current_stream() if x_in.is_cuda else None
+        nparts = min(k.SPLIT_FORWARD, B)
+        split = nparts > 1 and main is not None and not torch.cuda.is_current_stream_capturing()
+        if split:
+            auxs = [k.aux_stream(x_in.device, j) for j in range(nparts - 1)]
+            ev = torch.cuda.Event()
+            ev.record(main)
+            for aux in auxs:
+                aux.wait_event(ev)
+            cuts = [B * j // nparts for j in range(nparts + 1)]
+            parts = [((main if j == 0 else auxs[j - 1]), cuts[j], cuts[j + 1]) for j in range(nparts)]
+        else:
+            parts = [(None, 0, B)]
         x = x_in
         for i in range(g.depth):
             if before_block is not None:
-                before_block(i)
+                if split:
+                    before_block(i, also=auxs)
+                else:
+                    before_block(i)
             bw, p = ws.block(i), W[i]
-            k.layernorm_fwd(x, p["norm1.weight"], p["norm1.bias"], bw.ln1, bw.mean1, bw.rstd1, M, D)
-            k.linear_fwd(bw.ln1, p["attn.qkv.weight"], p["attn.qkv.bias"], bw.qkv, M, 3 * D, D)
-            k.attention_fwd(bw.qkv, bw.attn, bw.lse, B, N, g.heads, g.dh)
-            k.linear_fwd(bw.attn, p["attn.proj.weight"], p["attn.proj.bias"], bw.x_mid, M, D, D, EPI_RESIDUAL, resid=x)
-            k.layernorm_fwd(bw.x_mid, p["norm2.weight"], p["norm2.bias"], bw.ln2, bw.mean2, bw.rstd2, M, D)
-            k.linear_fwd(bw.ln2, p["mlp.fc1.weight"], p["mlp.fc1.bias"], bw.h_act, M, Hd, D, EPI_GELU, aux=bw.h_pre)
-            k.linear_fwd(bw.h_act, p["mlp.fc2.weight"], p["mlp.fc2.bias"], bw.x_out, M, D, Hd, EPI_RESIDUAL,
-                         resid=bw.x_mid)
+            for st, b0, b1 in parts:
+                r0, r1, Bh = b0 * N, b1 * N, b1 - b0
+                Mh = r1 - r0
+                h0, h1 = b0 * g.heads * N, b1 * g.heads * N
+                with (torch.cuda.stream(st) if st is not None and st is not main else contextlib.nullcontext()):
+                    xs = x[r0:r1]
+                    k.layernorm_fwd(xs, p["norm1.weight"], p["norm1.bias"], bw.ln1[r0:r1], bw.mean1[r0:r1], bw.rstd1[r0:r1],
+                                    Mh, D)
+                    k.linear_fwd(bw.ln1[r0:r1], p["attn.qkv.weight"], p["attn.qkv.bias"], bw.qkv[r0:r1], Mh, 3 * D, D)
+                    k.attention_fwd(bw.qkv[r0:r1], bw.attn[r0:r1], bw.lse[h0:h1], Bh, N, g.heads, g.dh)
+                    k.linear_fwd(bw.attn[r0:r1], p["attn.proj.weight"], p["attn.proj.bias"], bw.x_mid[r0:r1], Mh, D, D,
+                                 EPI_RESIDUAL, resid=xs)
+                    k.layernorm_fwd(bw.x_mid[r0:r1], p["norm2.weight"], p["norm2.bias"], bw.ln2[r0:r1], bw.mean2[r0:r1],
+                                    bw.rstd2[r0:r1], Mh, D)
+                    k.linear_fwd(bw.ln2[r0:r1], p["mlp.fc1.weight"], p["mlp.fc1.bias"], bw.h_act[r0:r1], Mh, Hd, D, EPI_GELU,
+                                 aux=bw.h_pre[r0:r1])
+                    k.linear_fwd(bw.h_act[r0:r1], p["mlp.fc2.weight"], p["mlp.fc2.bias"], bw.x_out[r0:r1], Mh, D, Hd,
+                                 EPI_RESIDUAL, resid=bw.x_mid[r0:r1])
             x = bw.x_out
+        if split:
+            for aux in auxs:
+                ev = torch.cuda.Event()
+                ev.record(aux)
+                main.wait_event(ev)
         return x
 
     def backward(self, ws: StackWorkspace, x_in: torch.Tensor, W, G, dx: torch.Tensor, dx_act: torch.Tensor,

@@ -107,10 +107,10 @@ class _Runtime:
         # in launch order; the forward waits for a block's range right before it reads the block's weights
         self.pending_updates: List[tuple] = []
 
-    def wait_updates(self, mat_through: Optional[int] = None) -> None:
-        """Make the current stream wait for pending optimizer updates: all of them (default), or every `vec` update
-        and the `mat` updates starting below offset `mat_through`.  The updates run in order on one stream, so waiting
-        for the last needed one covers everything launched before it."""
+    def wait_updates(self, mat_through: Optional[int] = None, also=()) -> None:
+        """Make the current stream (and the streams in `also`) wait for pending optimizer updates: all of them
+        (default), or every `vec` update and the `mat` updates starting below offset `mat_through`.  The updates run in
+        order on one stream, so waiting for the last needed one covers everything launched before it."""
         if not self.pending_updates:
             return
         last = -1
@@ -118,7 +118,10 @@ class _Runtime:
             if mat_through is None or r == "vec" or lo < mat_through:
                 last = j
         if last >= 0:
-            torch.cuda.current_stream().wait_event(self.pending_updates[last][3])
+            ev = self.pending_updates[last][3]
+            torch.cuda.current_stream().wait_event(ev)
+            for st in also:
+                st.wait_event(ev)
             del self.pending_updates[:last + 1]
 
     def block_end(self, prefix: str, i: int) -> int:
@@ -180,7 +183,7 @@ def _update_gate(rt: _Runtime, prefix: str):
     """before_block hook of BlockStack.forward: wait for the optimizer update of block i's weights (if one is pending)."""
     if not rt.pending_updates:
         return None
-    return lambda i: rt.wait_updates(mat_through=rt.block_end(prefix, i))
+    return lambda i, also=(): rt.wait_updates(mat_through=rt.block_end(prefix, i), also=also)
 
 
 def _plan_grads(rt: _Runtime, names: List[str], needs: List[bool]):
