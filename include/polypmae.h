@@ -128,9 +128,10 @@ int pm_mae_masking(const float* noise, int* ids_shuffle, int* ids_restore, float
  * emb f32 [B, 1+keep, D]; out f32 [B, 1+L, D]. */
 int pm_mae_unshuffle(const float* emb, const float* mask_token, const float* dpos, const int* ids_restore, float* out,
                      int B, int L, int keep, int D, void* stream);
-/* Backward: demb act-typed [B,1+keep,D] (pure gather through ids_shuffle); dmask_token f32 [D] (+=). */
+/* Backward: demb act-typed [B,1+keep,D] (pure gather through ids_shuffle); dmask_token f32 [D] (+=).
+ * workspace (>= 128*D*4 bytes) makes the mask-token sum two-stage and deterministic; NULL falls back to float atomics. */
 int pm_mae_unshuffle_bwd(const float* dout, const int* ids_shuffle, void* demb, int act_dtype, float* dmask_token,
-                         int B, int L, int keep, int D, void* stream);
+                         int B, int L, int keep, int D, void* workspace, size_t ws_bytes, void* stream);
 
 /* MAE reconstruction loss (models_mae.py:95-107,198-214): fused patchify + (optional norm_pix) + per-patch MSE.
  * pred f32 rows of `ldp` elements; row (b*(L+1)+1+l) holds patch l of sample b when has_cls_row=1 (the

@@ -33,7 +33,7 @@ SIGNATURES = {
     "pm_assemble_tokens_bwd": [P, P, P, I, P, P, I, I, I, P],
     "pm_mae_masking": [P, P, P, P, I, I, I, P],
     "pm_mae_unshuffle": [P, P, P, P, P, I, I, I, I, P],
-    "pm_mae_unshuffle_bwd": [P, P, P, I, P, I, I, I, I, P],
+    "pm_mae_unshuffle_bwd": [P, P, P, I, P, I, I, I, I, P, ctypes.c_size_t, P],
     "pm_mae_loss_fwd": [P, P, L, I, P, I, I, I, I, I, P],
     "pm_mae_loss_finish": [P, P, L, P, P, P],
     "pm_mae_loss_bwd": [P, P, L, I, P, P, P, P, I, I, I, I, I, I, P],

@@ -71,8 +71,11 @@ __global__ __launch_bounds__(256) void unshuffle_bwd_kernel(const float* __restr
 }
 
 // dmask_token[d] += sum over masked positions (j >= keep) of dout[b, 1 + ids_shuffle[b,j], d]
+// `partials` != NULL: block row blockIdx.y stores its sums there and mask_token_reduce_kernel adds the rows in a fixed
+// order (deterministic); NULL: one float atomic per column per block.
 __global__ __launch_bounds__(256) void mask_token_grad_kernel(const float* __restrict__ dout, const int* __restrict__ ids_shuffle,
-                                                              float* __restrict__ dmask_token, int B, int L, int keep, int D) {
+                                                              float* __restrict__ dmask_token, float* __restrict__ partials,
+                                                              int B, int L, int keep, int D) {
   __shared__ float red[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
@@ -90,7 +93,26 @@ __global__ __launch_bounds__(256) void mask_token_grad_kernel(const float* __res
   for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = acc[e];
   __syncthreads();
   const int t = threadIdx.x, cc = blockIdx.x * 256 + t;
-  if (cc < D) atomicAdd(dmask_token + cc, (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+  if (cc < D) {
+    const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (partials) partials[(long)blockIdx.y * D + cc] = v;
+    else atomicAdd(dmask_token + cc, v);
+  }
+}
+
+__global__ __launch_bounds__(1024) void mask_token_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out,
+                                                                 int rows, int D) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  red[rg][lane] = n < D ? strided_sum<8>(partials + n, D, rg, 16, rows) : 0.f;
+  __syncthreads();
+  if (rg == 0 && n < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][lane];
+    out[n] += t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -272,7 +294,8 @@ extern "C" int pm_mae_unshuffle(const float* emb, const float* mask_token, const
 }
 
 extern "C" int pm_mae_unshuffle_bwd(const float* dout, const int* ids_shuffle, void* demb, int act_dtype,
-                                    float* dmask_token, int B, int L, int keep, int D, void* stream) {
+                                    float* dmask_token, int B, int L, int keep, int D, void* workspace, size_t ws_bytes,
+                                    void* stream) {
   if (!dout || !ids_shuffle || !demb) return PM_EINVAL;
   if (B <= 0 || L <= 0 || keep <= 0 || keep > L || D <= 0 || (D & 3)) return PM_ESHAPE;
   const dim3 grid(cap_grid((long)B * (keep + 1), 4, 4096));
@@ -282,9 +305,15 @@ extern "C" int pm_mae_unshuffle_bwd(const float* dout, const int* ids_shuffle, v
     hipLaunchKernelGGL(unshuffle_bwd_kernel<float>, grid, dim3(256), 0, pm_stream(stream), dout, ids_shuffle, (float*)demb, B, L, keep, D);
   else
     return PM_EINVAL;
-  if (dmask_token && keep < L)
-    hipLaunchKernelGGL(mask_token_grad_kernel, dim3((D + 255) / 256, cap_grid((long)B * (L - keep), 64, 128)), dim3(256), 0,
-                       pm_stream(stream), dout, ids_shuffle, dmask_token, B, L, keep, D);
+  if (dmask_token && keep < L) {
+    const int rows = cap_grid((long)B * (L - keep), 64, 128);
+    float* partials = (workspace && ws_bytes >= (size_t)rows * D * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
+    hipLaunchKernelGGL(mask_token_grad_kernel, dim3((D + 255) / 256, rows), dim3(256), 0, pm_stream(stream), dout, ids_shuffle,
+                       dmask_token, partials, B, L, keep, D);
+    if (partials)
+      hipLaunchKernelGGL(mask_token_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, pm_stream(stream), partials, dmask_token,
+                         rows, D);
+  }
   return pm_check_launch();
 }
 

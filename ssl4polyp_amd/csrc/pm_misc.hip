@@ -281,19 +281,12 @@ __global__ __launch_bounds__(256) void cls_head_bwd_kernel(const float* __restri
   const float c2 = ((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3])) / (float)D;
   for (int d = tid; d < D; d += 256) {
     float g = 0.f;
-    for (int k = 0; k < n_class; ++k) {
-      const float dl = dlogits[(long)b * n_class + k];
-      g += dl * W[(long)k * D + d];
-      if (dW) atomicAdd(dW + (long)k * D + d, dl * xn[(long)b * D + d]);
-    }
+    for (int k = 0; k < n_class; ++k) g += dlogits[(long)b * n_class + k] * W[(long)k * D + d];
     const float xh = (xr[d] - mu) * rs;
-    if (dgamma) atomicAdd(dgamma + d, g * xh);
-    if (dbeta) atomicAdd(dbeta + d, g);
     const float o = rs * (g * gamma[d] - c1 - xh * c2);
     if (dx) dx[(long)b * sample + d] = o;
     if (dx_act) dx_act[(long)b * sample + d] = (T)o;
   }
-  if (dbias && tid < n_class) atomicAdd(dbias + tid, dlogits[(long)b * n_class + tid]);
   if (!dx) return;  // frozen backbone: nothing below the head needs a gradient
   // zero the gradient of every non-cls token of this sample
   const long rest = sample - D;
@@ -301,6 +294,42 @@ __global__ __launch_bounds__(256) void cls_head_bwd_kernel(const float* __restri
   for (long i = tid; i < (rest >> 2); i += 256) {
     *reinterpret_cast<f32x4*>(dx + (long)b * sample + D + 4 * i) = z;
     if (dx_act) store4<T>(dx_act + (long)b * sample + D + 4 * i, z);
+  }
+}
+
+// Parameter gradients of the head (lin_head weight / bias, final-norm gamma / beta): one thread per column walks the
+// samples in order -- a fixed summation order instead of one float atomic per (sample, column), so the whole training
+// step is reproducible bit for bit (B * (n_class + 3) loads per thread: a few microseconds).
+__global__ __launch_bounds__(256) void cls_head_pgrad_kernel(const float* __restrict__ dlogits, const float* __restrict__ x,
+                                                             long sample_stride, const float* __restrict__ W,
+                                                             const float* __restrict__ xn, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ dW,
+                                                             float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int B, int D, int n_class) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d < D) {
+    float sg = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float g = 0.f;
+      for (int k = 0; k < n_class; ++k) g += dlogits[(long)b * n_class + k] * W[(long)k * D + d];
+      const float xh = (x[(long)b * sample_stride + d] - mean[b]) * rstd[b];
+      sg += g * xh;
+      sb += g;
+    }
+    if (dgamma) dgamma[d] += sg;
+    if (dbeta) dbeta[d] += sb;
+    if (dW) {
+      for (int k = 0; k < n_class; ++k) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dlogits[(long)b * n_class + k] * xn[(long)b * D + d];
+        dW[(long)k * D + d] += s;
+      }
+    }
+  }
+  if (dbias && blockIdx.x == 0 && threadIdx.x < n_class) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogits[(long)b * n_class + threadIdx.x];
+    dbias[threadIdx.x] += s;
   }
 }
 
@@ -541,6 +570,9 @@ extern "C" int pm_cls_head_bwd(const float* dlogits, const float* x, int N, cons
                        mean, rstd, dx, (float*)dx_act, dW, dbias, dgamma, dbeta, D, n_class);
   else
     return PM_EINVAL;
+  if (dW || dbias || dgamma || dbeta)
+    hipLaunchKernelGGL(cls_head_pgrad_kernel, dim3((D + 255) / 256), dim3(256), 0, pm_stream(stream), dlogits, x, (long)N * D, W,
+                       xn, mean, rstd, dW, dbias, dgamma, dbeta, B, D, n_class);
   return pm_check_launch();
 }
 

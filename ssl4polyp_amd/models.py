@@ -435,9 +435,10 @@ class _MaeFn(torch.autograd.Function):
                                              True, acc_fn, cb_d)
         # -- un-shuffle + decoder_embed
         demb_act = torch.empty(Me, Dd, dtype=k.act_dtype, device=dev)
+        cs_ws = k._colsum_workspace(dev)  # partial rows of the mask-token sum (fixed-order second stage)
         _lib.check(k.lib.pm_mae_unshuffle_bwd(_ptr(dxd0), _ptr(ids_shuffle), _ptr(demb_act), k.act,
                                               _ptr(f.grad_view("mask_token")) if need("mask_token") else None, B, L, keep,
-                                              Dd, _stream()), "pm_mae_unshuffle_bwd")
+                                              Dd, _ptr(cs_ws), cs_ws.numel(), _stream()), "pm_mae_unshuffle_bwd")
         if need("decoder_embed.weight"):
             k.linear_wgrad(demb_act, latent, f.grad_view("decoder_embed.weight"), Me, Dd, De, accumulate)
         if need("decoder_embed.bias"):

@@ -378,8 +378,13 @@ def test_mae_masking_and_unshuffle():
     want.backward(dout)
     demb = torch.empty(B, keep + 1, D, device=DEV)
     dm = torch.zeros(D, device=DEV)
-    _lib.check(k.lib.pm_mae_unshuffle_bwd(_ptr(dout), _ptr(ids_shuffle), _ptr(demb), 0, _ptr(dm), B, L, keep, D, _stream()), "unshuffle_bwd")
-    assert rel(demb, er.grad) < 1e-6 and rel(dm, mr.grad) < 1e-5
+    ws = torch.empty(128 * D, device=DEV)
+    _lib.check(k.lib.pm_mae_unshuffle_bwd(_ptr(dout), _ptr(ids_shuffle), _ptr(demb), 0, _ptr(dm), B, L, keep, D, _ptr(ws),
+                                          ws.numel() * 4, _stream()), "unshuffle_bwd")
+    dm2 = torch.zeros_like(dm)
+    _lib.check(k.lib.pm_mae_unshuffle_bwd(_ptr(dout), _ptr(ids_shuffle), _ptr(demb), 0, _ptr(dm2), B, L, keep, D, None, 0,
+                                          _stream()), "unshuffle_bwd")  # atomics fallback
+    assert rel(demb, er.grad) < 1e-6 and rel(dm, mr.grad) < 1e-5 and rel(dm2, mr.grad) < 1e-5
 
 
 @pytest.mark.parametrize("norm_pix", [0, 1])
