@@ -282,7 +282,9 @@ def main():
             ks, gt, gf = kernel_stats(model, eager_step)
             dom = max(ks.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])
             roof["kernel"] = {"name": f"gemm_kernel<{args.precision},{dom[0]}>", **dom[1],
-                              "frac": round(dom[1]["tflops"] / peak, 4)}
+                              "frac": round(dom[1]["tflops"] / peak, 4),
+                              "note": "in-step launch times: launches of the two forward chains / of the dgrad and "
+                                      "weight-gradient streams overlap, so each shares the CUs (stand-alone rates: DESIGN.md)"}
             try:  # PMC traffic of the dominant kernel, from the committed rocprofv3 --pmc passes (profiles/)
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
                     t = json.load(fh).get(args.workload, {}).get(dom[0])
