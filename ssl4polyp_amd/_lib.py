@@ -49,6 +49,7 @@ SIGNATURES = {
 }
 
 TUNE_WGRAD_BLOCKS = 1
+ABI_VERSION = 2  # pm_abi_version() of the library these signatures describe
 
 _lib = None
 
@@ -71,6 +72,9 @@ def load():
     lib.pm_strerror.argtypes = [c_int]
     lib.pm_abi_version.restype = c_int
     lib.pm_abi_version.argtypes = []
+    if lib.pm_abi_version() != ABI_VERSION:  # a stale build would be called with the wrong argument lists
+        raise PolypMaeError(f"{LIB_PATH} has ABI version {lib.pm_abi_version()}, this package binds version {ABI_VERSION}: "
+                            "rebuild with `python -c 'import __graft_entry__ as g; g.build(force=True)'`")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = c_int

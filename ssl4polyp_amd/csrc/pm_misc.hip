@@ -638,4 +638,4 @@ extern "C" const char* pm_strerror(int status) {
   }
 }
 
-extern "C" int pm_abi_version(void) { return 1; }
+extern "C" int pm_abi_version(void) { return 2; }  // 2: pm_mae_unshuffle_bwd workspace, pm_gemm_colsum, pm_preprocess_u8, pm_tune

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(built):
     from ssl4polyp_amd import _lib
     assert set(_lib.SIGNATURES) | {"pm_strerror", "pm_abi_version"} == set(names)
     handle = _lib.load()
-    assert handle.pm_abi_version() == 1
+    assert handle.pm_abi_version() == 2
     assert handle.pm_strerror(-2).decode() == "unsupported shape"
 
 
