@@ -4,7 +4,7 @@
 //
 //   acc[m,n] = sum_k X(m,k) * W(n,k)        X = "A" matrix (M side), W = "B" matrix (N side)
 //
-// Tile: 128(m) x 128(n) x 128 BYTES of k (64 bf16 / 32 f32) per step, 256 threads = 4 wave64 in 2x2, each
+// 128x128 kernels -- tile: 128(m) x 128(n) x 128 BYTES of k (64 bf16 / 32 f32) per step, 256 threads = 4 wave64 in 2x2, each
 // wave owns 64x64 = 2x2 accumulators of v_mfma_f32_32x32x16_bf16 (or 4x v_mfma_f32_32x32x2_f32 per 16-B
 // fragment in f32 mode: exact f32 fma chain).  The W fragment is the MFMA's first operand, so the
 // accumulator has n in registers (4 consecutive n per register quad) and m on the lane.
@@ -17,8 +17,12 @@
 //   -> forward: X k-normal, W k-normal;  dgrad: dY k-normal, W (as stored [out][in]) k-major;
 //      wgrad: dY k-major (M side = out features), X k-major (N side = in features).
 //
-// Two kernels share the LDS images and the fragment readers:
-//   gemm_glds_kernel (fast path, K % k-step == 0): global -> LDS by LDS-DMA (global_load_lds_dwordx4; the LDS
+// Three kernels:
+//   gemm_v3_kernel (below, "large-tile path"): the bf16 workhorse of the training step -- 256x256 / 192x256 / 256x128
+//     block tiles, 8 waves, 4-slot LDS-DMA ring, ping-pong or software-pipelined k-loop, batched-load / 16-B-store
+//     epilogues; forward, dgrad and split-K wgrad of every ViT-B shape go through it.
+//   The two 128x128 kernels serve f32 mode and the small / odd shapes, and share LDS images and fragment readers:
+//   gemm_glds_kernel (K % k-step == 0): global -> LDS by LDS-DMA (global_load_lds_dwordx4; the LDS
 //     image is lane-linear, so the swizzle is applied to each lane's SOURCE address), double buffered, one
 //     barrier per k-step, no staging registers and no ds_write; rows beyond M / N are clamped to the last
 //     valid row (their results are never stored).  Optional split-K over blockIdx.y writes f32 partial slabs
