@@ -52,6 +52,7 @@ class DevicePrefetcher:
         self.loader, self.device = loader, torch.device(device)
         self.mean, self.std, self.flip_p, self.generator = mean, std, float(flip_p), generator
         self._pinned = [None, None]
+        self._flip_pin = [None, None]   # per slot: pinned flip flags
         self._dev = [None, None]        # per slot: (uint8 frames, float32 images) on the device
         self._consumed = [None, None]   # per slot: event recorded on the consumer's stream after it used the batch
         self._stream: Optional[torch.cuda.Stream] = None
@@ -74,7 +75,13 @@ class DevicePrefetcher:
         flips = None
         if self.flip_p > 0:
             r = torch.rand(2, frames.shape[0], generator=self.generator)
-            flips = ((r[0] < self.flip_p).to(torch.uint8) | ((r[1] < self.flip_p).to(torch.uint8) << 1))
+            f8 = ((r[0] < self.flip_p).to(torch.uint8) | ((r[1] < self.flip_p).to(torch.uint8) << 1))
+            # pinned too: a pageable host-to-device copy is synchronous and would stall the enqueue of the step
+            flips = self._flip_pin[slot]
+            if flips is None or flips.numel() != f8.numel():
+                flips = torch.empty(f8.numel(), dtype=torch.uint8).pin_memory()
+                self._flip_pin[slot] = flips
+            flips.copy_(f8)
         # device buffers are owned per slot and reused (no allocator traffic on the copy stream): the copy stream first
         # waits until the consumer's work on the batch that last used this slot has been enqueued AND executed
         bufs = self._dev[slot]
