@@ -231,13 +231,15 @@ def main():
     else:
         step = eager_step
 
+    host_pool, host_gen = [], torch.Generator().manual_seed(1234 + rank)
+    if args.input == "host":  # four decoded batches in pinned host memory, built outside the timed region
+        host_pool = [(torch.randint(0, 256, (batch, 224, 224, 3), dtype=torch.uint8, generator=host_gen).pin_memory(),
+                      (torch.rand(batch, generator=host_gen) < 0.5).long().pin_memory()) for _ in range(4)]
+
     def host_feed(n):
         # uint8 HWC frames + labels in pinned host memory -> DevicePrefetcher (H2D + flips + ToTensor + Normalize)
         from ssl4polyp_amd.data import DevicePrefetcher
-        g = torch.Generator().manual_seed(1234 + rank)
-        pool = [(torch.randint(0, 256, (batch, 224, 224, 3), dtype=torch.uint8, generator=g).pin_memory(),
-                 (torch.rand(batch, generator=g) < 0.5).long().pin_memory()) for _ in range(4)]
-        return DevicePrefetcher([pool[i % 4] for i in range(n)], device, flip_p=0.5, generator=g)
+        return DevicePrefetcher([host_pool[i % 4] for i in range(n)], device, flip_p=0.5, generator=host_gen)
 
     if args.input == "host":
         if use_graph:

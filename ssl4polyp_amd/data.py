@@ -9,6 +9,7 @@ Normalize -- bit-exact with torchvision's float32 arithmetic.
 """
 from __future__ import annotations
 
+import concurrent.futures
 from typing import Iterable, Iterator, Optional, Sequence, Tuple
 
 import torch
@@ -107,28 +108,39 @@ class DevicePrefetcher:
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=self.device)
         it = iter(self.loader)
-        slot = 0
+        # Staging runs on a worker thread: the pinned-memory copy and the host-to-device enqueue block their caller for
+        # about as long as a CPU memcpy of the batch (1 ms per 64 frames measured), and the main thread must spend that
+        # time enqueueing the training step instead.
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+
+        def job(slot, batch):
+            torch.cuda.set_device(self.device)
+            if self._pinned[slot] is not None:  # this staging slot was last read by the copy issued two batches ago
+                self._stream.synchronize()
+            return self._stage(slot, batch)
+
         try:
-            nxt = self._stage(slot, next(it))
-        except StopIteration:
-            return
-        while nxt is not None:
-            imgs, rest, ev = nxt
-            cur, slot = slot, slot ^ 1
+            slot = 0
             try:
-                # the pinned staging slot we are about to overwrite was last read by the copy issued two batches ago
-                if self._pinned[slot] is not None:
-                    self._stream.synchronize()
-                nxt = self._stage(slot, next(it))
+                fut = pool.submit(job, slot, next(it))
             except StopIteration:
-                nxt = None
-            main = torch.cuda.current_stream(self.device)
-            main.wait_event(ev)
-            for t in rest:
-                if torch.is_tensor(t):
-                    t.record_stream(main)
-            yield (imgs,) + rest
-            # the consumer has enqueued its work on this batch: the slot's buffers may be refilled once that work ran
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(self.device))
-            self._consumed[cur] = done
+                return
+            while fut is not None:
+                imgs, rest, ev = fut.result()
+                cur, slot = slot, slot ^ 1
+                try:
+                    fut = pool.submit(job, slot, next(it))
+                except StopIteration:
+                    fut = None
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(ev)
+                for t in rest:
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
+                yield (imgs,) + rest
+                # the consumer has enqueued its work on this batch: the slot's buffers may be refilled once that work ran
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self.device))
+                self._consumed[cur] = done
+        finally:
+            pool.shutdown(wait=True)
