@@ -11,8 +11,9 @@ into one flat f32 range in forward order and finishes it back-to-front during ba
   * each ``all_reduce`` is issued on a side HIP stream fenced by an event recorded on the compute
     stream, so RCCL runs under the remaining backward; the compute stream only waits (stream-side, no host
     block) right before the optimizer reads the gradients;
-  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default 64 MiB) so each ring
-    step moves >= 8 MiB per link, and there are only ~6 collectives per step.
+  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default 32 MiB: each ring step still
+    moves >= 4 MiB per link, ~11 collectives per step) -- the last bucket is the only one the backward cannot
+    hide, so its size is the exposed tail.
 Gradients are summed; the mean is folded into the fused AdamW (``grad_scale = 1/world``).
 """
 from __future__ import annotations
@@ -25,7 +26,7 @@ import torch.nn as nn
 
 
 class GradSync:
-    def __init__(self, rt, process_group=None, bucket_mb: float = 64.0):
+    def __init__(self, rt, process_group=None, bucket_mb: float = 32.0):
         self.rt = rt
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
@@ -89,7 +90,7 @@ class GradSync:
 class DataParallel(nn.Module):
     """Thin wrapper: broadcast parameters from rank 0, attach the gradient synchroniser to the module's runtime."""
 
-    def __init__(self, module: nn.Module, device: torch.device, process_group=None, bucket_mb: float = 64.0):
+    def __init__(self, module: nn.Module, device: torch.device, process_group=None, bucket_mb: float = 32.0):
         super().__init__()
         self.module = module
         module.to(device)
