@@ -11,8 +11,9 @@ into one flat f32 range in forward order and finishes it back-to-front during ba
   * each ``all_reduce`` is issued on a side HIP stream fenced by an event recorded on the compute
     stream, so RCCL runs under the remaining backward; the compute stream only waits (stream-side, no host
     block) right before the optimizer reads the gradients;
-  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default 32 MiB: each ring step still
-    moves >= 4 MiB per link, ~11 collectives per step) -- the last bucket is the only one the backward cannot
+  * xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large but no larger than one transformer block
+    (default 24 MiB < the 28 MiB of a ViT-B block's matrices, so a bucket closes at every block boundary: 12-13
+    collectives per step, >= 3.5 MiB per link per ring step) -- the last bucket is the only one the backward cannot
     hide, so its size is the exposed tail.
 Gradients are summed; the mean is folded into the fused AdamW (``grad_scale = 1/world``).
 """
@@ -26,7 +27,7 @@ import torch.nn as nn
 
 
 class GradSync:
-    def __init__(self, rt, process_group=None, bucket_mb: float = 32.0):
+    def __init__(self, rt, process_group=None, bucket_mb: float = 24.0):
         self.rt = rt
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
@@ -90,7 +91,7 @@ class GradSync:
 class DataParallel(nn.Module):
     """Thin wrapper: broadcast parameters from rank 0, attach the gradient synchroniser to the module's runtime."""
 
-    def __init__(self, module: nn.Module, device: torch.device, process_group=None, bucket_mb: float = 32.0):
+    def __init__(self, module: nn.Module, device: torch.device, process_group=None, bucket_mb: float = 24.0):
         super().__init__()
         self.module = module
         module.to(device)
