@@ -4,7 +4,7 @@ import torch
 from ssl4polyp_amd.engine import Kernels
 from ssl4polyp_amd._lib import EPI_STORE, EPI_RESIDUAL, EPI_GELU, EPI_DGELU
 k = Kernels("bf16"); k.lib.pm_debug_gemm_config.argtypes = [ctypes.c_int]
-dev="cuda"; M=int(os.environ.get("M", 12608)); D=768; H=3072; bf=torch.bfloat16
+dev="cuda"; M=int(os.environ.get("M", 12608)); D=int(os.environ.get("D", 768)); H=4*D; bf=torch.bfloat16
 CFGS = [int(c) for c in os.environ.get("CFGS", "0,16,17,18,19,20,21").split(",")]
 def t(*s, dt=bf): return (torch.randn(*s, device=dev) * 0.5).to(dt)
 x, x3, xh = t(M, D), t(M, 3*D), t(M, H); Wqkv, Wproj, W1, W2 = t(3*D, D), t(D, D), t(H, D), t(D, H)
