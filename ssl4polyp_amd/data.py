@@ -56,6 +56,7 @@ class DevicePrefetcher:
         self._flip_pin = [None, None]   # per slot: pinned flip flags
         self._dev = [None, None]        # per slot: (uint8 frames, float32 images) on the device
         self._consumed = [None, None]   # per slot: event recorded on the consumer's stream after it used the batch
+        self._slot_copied = [None, None]  # per slot: event after the slot's host-to-device copies were enqueued
         self._stream: Optional[torch.cuda.Stream] = None
 
     def __len__(self):
@@ -100,6 +101,7 @@ class DevicePrefetcher:
             rest_dev = tuple(t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in rest)
             ev = torch.cuda.Event()
             ev.record(self._stream)
+            self._slot_copied[slot] = ev
         return imgs, rest_dev, ev
 
     def __iter__(self) -> Iterator:
@@ -115,8 +117,10 @@ class DevicePrefetcher:
 
         def job(slot, batch):
             torch.cuda.set_device(self.device)
-            if self._pinned[slot] is not None:  # this staging slot was last read by the copy issued two batches ago
-                self._stream.synchronize()
+            # this slot's pinned buffers (frames and / or flip flags) were last read by the copies issued two batches ago,
+            # which wait on the consumer's event and may not have executed yet: drain them before the host rewrites them
+            if self._slot_copied[slot] is not None:
+                self._slot_copied[slot].synchronize()
             return self._stage(slot, batch)
 
         try:

@@ -576,9 +576,12 @@ def mae_vit_large_patch16_dec512d8b(**kwargs):
 
 
 def mae_vit_huge_patch14_dec512d8b(**kwargs):
-    return MaskedAutoencoderViT(patch_size=14, embed_dim=1280, depth=32, num_heads=16, decoder_embed_dim=512,
-                                decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
-                                norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+    """models_mae.py:239-244.  Not runnable on the HIP path: the row-in-registers LayerNorm kernels stop at D = 1024
+    (ViT-H is 1280) and a 14x14 patch gives a 588-element im2col row, which is not a multiple of the 16-byte chunks the
+    bf16 GEMM loads.  No shipped config of the reference uses it (run_hyperkvasir_pretraining.py:96 fixes
+    mae_vit_base_patch16), so the factory fails at construction instead of at the first forward."""
+    raise NotImplementedError("mae_vit_huge_patch14 is outside the MI355X hot path (LayerNorm kernels: D <= 1024; "
+                              "patch 14 -> K = 588 is not 16-byte aligned in bf16); use the base or large factory")
 
 
 mae_vit_base_patch16 = mae_vit_base_patch16_dec512d8b
@@ -620,7 +623,9 @@ class ViT_from_MAE(_ClassifierBase):
                                     decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
                                     norm_layer=norm_layer)
         if weight_path is not None:
-            weights = torch.load(weight_path, map_location="cpu")["model"]
+            # the MAE checkpoint also pickles an argparse.Namespace under "args" (misc.py:311-318): a trusted local file,
+            # read the way torch 1.9's torch.load did (full unpickle)
+            weights = torch.load(weight_path, map_location="cpu", weights_only=False)["model"]
             own = full.state_dict()
             n = 0
             for name, param in weights.items():
@@ -687,8 +692,14 @@ class VisionTransformer_from_Any(_ClassifierBase):
                 nn.init.zeros_(m.bias)
                 nn.init.ones_(m.weight)
         if ImageNet_weights:
-            raise NotImplementedError("ImageNet_weights=True downloads an augreg .npz from storage.googleapis.com "
-                                      "(models.py:51-55); load a local checkpoint with load_pretrained() instead")
+            # models.py:51-55 downloads B_16-i21k-...-res_224.npz from storage.googleapis.com; there is no network on this
+            # path, so the same file is taken from a local path: ImageNet_weights="<file.npz>" or $SSL4POLYP_AUGREG_NPZ
+            import os
+            loc = ImageNet_weights if isinstance(ImageNet_weights, (str, os.PathLike)) else os.environ.get("SSL4POLYP_AUGREG_NPZ")
+            if not loc or not os.path.exists(str(loc)):
+                raise FileNotFoundError("ImageNet_weights=True needs the augreg ViT-B/16 .npz of models.py:51-55 on local disk: "
+                                        "pass its path as ImageNet_weights or set SSL4POLYP_AUGREG_NPZ (no download here)")
+            self.load_pretrained(loc)
         self.head = nn.Identity()
         self.head_bool = head
         if head:
@@ -702,7 +713,9 @@ class VisionTransformer_from_Any(_ClassifierBase):
 
     def load_pretrained(self, checkpoint_path):
         """models.py:68-115 for torch checkpoints (dict with state_dict/model/... or a bare state dict)."""
-        checkpoint = torch.load(str(checkpoint_path), map_location="cpu")
+        if str(checkpoint_path).lower().endswith(".npz"):
+            return load_augreg_npz(self, str(checkpoint_path))
+        checkpoint = torch.load(str(checkpoint_path), map_location="cpu", weights_only=False)
         state_dict = None
         if isinstance(checkpoint, dict):
             for key in ("state_dict", "model", "model_state", "weights", "params"):
@@ -722,6 +735,58 @@ class VisionTransformer_from_Any(_ClassifierBase):
 
     def forward(self, x):
         return self._classify(x)
+
+
+def load_augreg_npz(model, path: str, prefix: str = "") -> None:
+    """Official JAX / augreg ViT checkpoint (.npz) -> this module's parameters: the mapping of timm 0.4.12
+    ``vision_transformer._load_weights`` (absent dependency, restated), which the reference calls for SUP-imnet
+    (models.py:68-77).  Dense kernels are stored [in, out], attention query/key/value kernels [D, H, dh], the
+    attention output kernel [H, dh, D], the patch embedding HWIO."""
+    w = np.load(path)
+    if not prefix and "opt/target/embedding/kernel" in w:
+        prefix = "opt/target/"
+
+    def t(a):  # numpy kernel -> torch weight layout
+        if a.ndim == 4:
+            a = a.transpose(3, 2, 0, 1)
+        elif a.ndim == 3:
+            a = a.transpose(2, 0, 1)
+        elif a.ndim == 2:
+            a = a.transpose(1, 0)
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    def raw(a):
+        return torch.from_numpy(np.ascontiguousarray(a))
+
+    with torch.no_grad():
+        ew = t(w[f"{prefix}embedding/kernel"])
+        if ew.shape != model.patch_embed.proj.weight.shape:
+            raise ValueError(f"patch embedding {tuple(ew.shape)} does not fit {tuple(model.patch_embed.proj.weight.shape)}")
+        model.patch_embed.proj.weight.copy_(ew)
+        model.patch_embed.proj.bias.copy_(raw(w[f"{prefix}embedding/bias"]))
+        model.cls_token.copy_(raw(w[f"{prefix}cls"]).reshape(model.cls_token.shape))
+        pos = raw(w[f"{prefix}Transformer/posembed_input/pos_embedding"])
+        if pos.shape != model.pos_embed.shape:
+            raise ValueError(f"pos_embedding {tuple(pos.shape)} != {tuple(model.pos_embed.shape)} (bicubic resize of the "
+                             "table is not on this path: the reference runs at 224^2 / patch 16)")
+        model.pos_embed.copy_(pos)
+        model.norm.weight.copy_(raw(w[f"{prefix}Transformer/encoder_norm/scale"]))
+        model.norm.bias.copy_(raw(w[f"{prefix}Transformer/encoder_norm/bias"]))
+        for i, blk in enumerate(model.blocks.children()):
+            bp = f"{prefix}Transformer/encoderblock_{i}/"
+            mp = bp + "MultiHeadDotProductAttention_1/"
+            blk.norm1.weight.copy_(raw(w[bp + "LayerNorm_0/scale"]))
+            blk.norm1.bias.copy_(raw(w[bp + "LayerNorm_0/bias"]))
+            blk.attn.qkv.weight.copy_(torch.cat([raw(w[f"{mp}{n}/kernel"]).flatten(1).T for n in ("query", "key", "value")]))
+            blk.attn.qkv.bias.copy_(torch.cat([raw(w[f"{mp}{n}/bias"]).reshape(-1) for n in ("query", "key", "value")]))
+            blk.attn.proj.weight.copy_(t(w[mp + "out/kernel"]).flatten(1))
+            blk.attn.proj.bias.copy_(raw(w[mp + "out/bias"]))
+            for r in range(2):
+                fc = getattr(blk.mlp, f"fc{r + 1}")
+                fc.weight.copy_(t(w[f"{bp}MlpBlock_3/Dense_{r}/kernel"]))
+                fc.bias.copy_(raw(w[f"{bp}MlpBlock_3/Dense_{r}/bias"]))
+            blk.norm2.weight.copy_(raw(w[bp + "LayerNorm_2/scale"]))
+            blk.norm2.bias.copy_(raw(w[bp + "LayerNorm_2/bias"]))
 
 
 # factories with the reference's names / signatures (src/ssl4polyp/utils/__init__.py:29-67)

@@ -117,7 +117,26 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._hyper[gi, 6] = float(group.get("step", 0))
             self._hyper_host = None
         if force or rows != self._hyper_host:
-            self._hyper[:, :6].copy_(torch.tensor(rows, dtype=torch.float32), non_blocking=False)
+            # The MAE loop changes lr EVERY iteration (engine_pretrain.py:47-48): the upload must not block the host, or
+            # each step would wait for the whole backward to drain before AdamW and the next forward can be enqueued.
+            # Pinned staging slots, asynchronous copy on the current stream, one event per slot (a slot is rewritten
+            # only after its previous copy has executed: four steps of run-ahead before the host could ever wait here).
+            if f.device.type == "cuda":
+                if getattr(self, "_hyper_pin", None) is None or self._hyper_pin[0].shape[0] != len(rows):
+                    self._hyper_pin = [torch.empty(len(rows), 6, dtype=torch.float32).pin_memory() for _ in range(4)]
+                    self._hyper_pin_ev = [None] * 4
+                    self._hyper_slot = 0
+                i = self._hyper_slot
+                self._hyper_slot = (i + 1) % 4
+                if self._hyper_pin_ev[i] is not None:
+                    self._hyper_pin_ev[i].synchronize()
+                self._hyper_pin[i].copy_(torch.tensor(rows, dtype=torch.float32))
+                self._hyper[:, :6].copy_(self._hyper_pin[i], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(f.device))
+                self._hyper_pin_ev[i] = ev
+            else:
+                self._hyper[:, :6].copy_(torch.tensor(rows, dtype=torch.float32))
             self._hyper_host = rows
 
     @torch.no_grad()

@@ -257,23 +257,82 @@ def _is_main() -> bool:
     return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
 
 
-def save_mae_checkpoint(output_dir, epoch: int, model, optimizer, args, scaler_state: Optional[dict] = None) -> Path:
+def grad_scaler_state() -> dict:
+    """What an enabled ``torch.cuda.amp.GradScaler`` serialises (its initial values).  bf16 needs no loss scaling, but
+    the reference's resume paths call ``scaler.load_state_dict(ckpt[...])`` on an ENABLED scaler (misc.py:349-350,
+    tc.py:5978), which rejects an empty dict -- so the checkpoints carry a well-formed one."""
+    return {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
+
+
+def _host_state_dict(model) -> Dict[str, torch.Tensor]:
+    return {k: v.detach().cpu() for k, v in _unwrap(model).state_dict().items()}
+
+
+def _symlink_pointer(pointer: Path, target: Path) -> None:
+    """tc.py:3929-3940 _update_checkpoint_pointer / misc.py:323-333: relative symlink, copy when links are refused."""
+    import shutil
+    pointer.parent.mkdir(parents=True, exist_ok=True)
+    try:
+        if pointer.is_symlink() or pointer.exists():
+            pointer.unlink()
+        pointer.symlink_to(target.name)
+    except OSError:
+        shutil.copy2(target, pointer)
+
+
+class AsyncCheckpointWriter:
+    """Takes ``torch.save`` (pickling + disk) off the training thread: the caller hands over a payload whose tensors are
+    already host copies; one background thread writes `<path>.tmp`, renames it and then moves the pointer.  `wait()`
+    joins outstanding writes (call it before reading a checkpoint back or at exit).  The reference saves synchronously
+    on rank 0 while every other rank sits in the barrier behind it (tc.py:7036-7111 + 7246; misc.py:306-335)."""
+
+    def __init__(self):
+        import concurrent.futures
+        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        self._pending: List = []
+
+    def submit(self, payload: dict, path: Path, pointer: Optional[Path] = None):
+        def job():
+            tmp = path.with_name(path.name + ".tmp")
+            torch.save(payload, tmp)
+            os.replace(tmp, path)
+            if pointer is not None:
+                _symlink_pointer(pointer, path)
+            return path
+        fut = self._pool.submit(job)
+        self._pending.append(fut)
+        return fut
+
+    def wait(self) -> None:
+        pend, self._pending = self._pending, []
+        for f in pend:
+            f.result()
+
+    def close(self) -> None:
+        self.wait()
+        self._pool.shutdown(wait=True)
+
+
+def _write(payload: dict, path: Path, pointer: Optional[Path], writer: Optional[AsyncCheckpointWriter]) -> None:
+    path.parent.mkdir(parents=True, exist_ok=True)
+    if writer is not None:
+        writer.submit(payload, path, pointer)
+        return
+    torch.save(payload, path)
+    if pointer is not None:
+        _symlink_pointer(pointer, path)
+
+
+def save_mae_checkpoint(output_dir, epoch: int, model, optimizer, args, scaler_state: Optional[dict] = None,
+                        writer: Optional[AsyncCheckpointWriter] = None) -> Path:
     """misc.py:306-335: <out>/checkpoint-<epoch>.pth = {model, optimizer, epoch, scaler, args} + last.pth symlink.
-    (`scaler` is kept for format compatibility: bf16 needs no loss scaling.)"""
+    `scaler` holds a GradScaler-shaped dict (see grad_scaler_state) so that the reference's load_model accepts the file."""
     out = Path(output_dir)
     path = out / f"checkpoint-{epoch}.pth"
     if _is_main():
-        out.mkdir(parents=True, exist_ok=True)
-        to_save = {"model": {k: v.detach().cpu() for k, v in _unwrap(model).state_dict().items()},
-                   "optimizer": optimizer.state_dict(), "epoch": epoch, "scaler": scaler_state or {}, "args": args}
-        torch.save(to_save, path)
-        last = out / "last.pth"
-        try:
-            if last.is_symlink() or last.exists():
-                last.unlink()
-            last.symlink_to(path.name)
-        except OSError:
-            pass
+        to_save = {"model": _host_state_dict(model), "optimizer": optimizer.state_dict(), "epoch": epoch,
+                   "scaler": scaler_state if scaler_state else grad_scaler_state(), "args": args}
+        _write(to_save, path, out / "last.pth", writer)
     return path
 
 
@@ -290,26 +349,107 @@ def load_mae_checkpoint(path, model, optimizer=None, args=None) -> int:
     return start
 
 
+def cls_checkpoint_name(stem: str, epoch: int, selection_tag: str = "best") -> str:
+    """tc.py:7089-7091: `<stem>_e<EE>_<tag>.pth` (the pointer is `<stem>.pth`)."""
+    return f"{stem}_e{epoch:02d}_{selection_tag}.pth"
+
+
+def find_existing_checkpoint(stem_path):
+    """tc.py:3914-3926 _find_existing_checkpoint: the `<stem>.pth` pointer if present, else the newest `<stem>_e*_*.pth`.
+    Returns (path | None, pointer_valid)."""
+    stem_path = Path(stem_path)
+    pointer = stem_path.with_suffix(".pth") if stem_path.suffix != ".pth" else stem_path
+    stem_path = pointer.with_suffix("")
+    if pointer.exists() or pointer.is_symlink():
+        return pointer, True
+    if not stem_path.parent.exists():
+        return None, False
+    cands = sorted(stem_path.parent.glob(f"{stem_path.name}_e*_*.pth"))
+    return (cands[-1], False) if cands else (None, False)
+
+
 def save_cls_checkpoint(path, epoch: int, model, optimizer, scheduler=None, loss: Optional[float] = None,
-                        extra: Optional[dict] = None) -> Path:
-    """tc.py:7036-7067 payload keys (model_state_dict / optimizer_state_dict / scaler_state_dict / scheduler_state_dict
-    / epoch / loss + RNG states); `extra` carries the reference's val_* / monitor_* / threshold fields unchanged."""
+                        extra: Optional[dict] = None, pointer=None, writer: Optional[AsyncCheckpointWriter] = None) -> Path:
+    """tc.py:7036-7111 payload: epoch / model_state_dict / optimizer_state_dict / scaler_state_dict / loss /
+    py_state / np_state / torch_state (+ scheduler_state_dict only when a scheduler exists, tc.py:7065-7066); `extra`
+    carries the reference's val_* / monitor_* / threshold fields unchanged.  `pointer`: the `<stem>.pth` link to move
+    onto this file (tc.py:7111)."""
     import random
 
     import numpy as np
     path = Path(path)
     if _is_main():
-        path.parent.mkdir(parents=True, exist_ok=True)
-        payload = {"epoch": epoch, "model_state_dict": {k: v.detach().cpu() for k, v in _unwrap(model).state_dict().items()},
-                   "optimizer_state_dict": optimizer.state_dict(), "scaler_state_dict": {},
-                   "scheduler_state_dict": scheduler.state_dict() if scheduler is not None else None, "loss": loss,
-                   "python_random_state": random.getstate(), "numpy_random_state": np.random.get_state(),
-                   "torch_rng_state": torch.get_rng_state()}
-        if torch.cuda.is_available():
-            payload["cuda_rng_state_all"] = torch.cuda.get_rng_state_all()
+        payload = {"epoch": epoch, "model_state_dict": _host_state_dict(model),
+                   "optimizer_state_dict": optimizer.state_dict(), "scaler_state_dict": grad_scaler_state(), "loss": loss,
+                   "py_state": random.getstate(), "np_state": np.random.get_state(), "torch_state": torch.get_rng_state()}
+        if scheduler is not None:
+            payload["scheduler_state_dict"] = scheduler.state_dict()
         payload.update(extra or {})
-        torch.save(payload, path)
+        _write(payload, path, Path(pointer) if pointer is not None else None, writer)
     return path
+
+
+@dataclass
+class ClsResume:
+    start_epoch: int = 1
+    best_val_perf: Optional[float] = None
+    resume_monitor_available: bool = False
+    thresholds: Dict = field(default_factory=dict)
+    threshold_records: Dict = field(default_factory=dict)
+    source: Optional[Path] = None
+    from_parent: bool = False
+
+
+def load_cls_checkpoint(stem_path, model, optimizer=None, scheduler=None, parent_checkpoint=None,
+                        restore_rng: bool = True) -> ClsResume:
+    """tc.py:5667-5714 + 5976-5980: resume from `<stem>.pth` / the newest `<stem>_e*_*.pth` (model, optimizer, scheduler,
+    Python / NumPy / torch RNG streams, monitor value, thresholds; repairs a missing pointer), else start from a parent
+    run's weights (`parent_checkpoint`: payload with model_state_dict or a bare state dict), else a fresh start."""
+    import random
+
+    import numpy as np
+    info = ClsResume()
+    existing, pointer_valid = find_existing_checkpoint(stem_path)
+    if existing is not None:
+        main = torch.load(str(existing), map_location="cpu", weights_only=False)
+        _unwrap(model).load_state_dict(main["model_state_dict"])
+        info.start_epoch = int(main["epoch"]) + 1
+        monitor = main.get("monitor_value")
+        if monitor is None and "val_loss" in main:
+            monitor = main.get("val_loss")
+        if monitor is None:
+            monitor = main.get("val_perf")
+        else:
+            info.resume_monitor_available = True
+        info.best_val_perf = monitor
+        if restore_rng:
+            random.setstate(main["py_state"])
+            np.random.set_state(main["np_state"])
+            torch.set_rng_state(main["torch_state"])
+        info.thresholds = dict(main.get("thresholds", {}) or {})
+        info.threshold_records = dict(main.get("threshold_records", {}) or {})
+        info.source = Path(existing)
+        if not pointer_valid:
+            stem = Path(stem_path)
+            _symlink_pointer(stem if stem.suffix == ".pth" else stem.with_suffix(".pth"), Path(existing))
+        if info.best_val_perf is not None:  # tc.py:5976-5980
+            if optimizer is not None and "optimizer_state_dict" in main:
+                optimizer.load_state_dict(main["optimizer_state_dict"])
+            if scheduler is not None and "scheduler_state_dict" in main:
+                scheduler.load_state_dict(main["scheduler_state_dict"])
+        return info
+    if parent_checkpoint:
+        parent = Path(parent_checkpoint).expanduser()
+        if not parent.exists():
+            raise FileNotFoundError(f"Parent checkpoint '{parent_checkpoint}' does not exist.")
+        state = torch.load(str(parent), map_location="cpu", weights_only=False)
+        if isinstance(state, dict) and "model_state_dict" in state:
+            info.thresholds = dict(state.get("thresholds", {}) or {})
+            info.threshold_records = dict(state.get("threshold_records", {}) or {})
+            state = state["model_state_dict"]
+        _unwrap(model).load_state_dict(state)
+        info.source, info.from_parent = parent, True
+    return info
 
 
 # ---------------------------------------------------------------------------------------------------
