@@ -5,22 +5,27 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = zero_grad -> forward -> loss -> backward (-> RCCL gradient all-reduce) -> fused AdamW, inputs
-resident in HBM.  Default workload = BASELINE.json configs[1]: ViT-B/16 classification
-fine-tune, bf16, bs=64/GPU, 224^2.  Rank 0 prints ONE JSON line (contract in the task statement) carrying
-`roofline` (achieved algorithmic TFLOP/s vs the 2.5 PFLOP/s dense bf16 MFMA peak, plus the dominant
-kernel's own live-measured average duration) and `cpu_baseline` (the CPU oracle timed on this host).
+resident in HBM.  Headline workload = BASELINE.json configs[1]: ViT-B/16 classification
+fine-tune, bf16, bs=64/GPU, 224^2; BASELINE.json's metric names both halves ("MAE pretrain + cls finetune"), so
+the default run also measures configs[2] (MAE pre-train, mask 0.75, bs=256/GPU) in the same process and reports it
+as the `mae` sub-record.  Rank 0 prints ONE JSON line (contract in the task statement) carrying
+  `roofline`      achieved algorithmic TFLOP/s vs the 2.5 PFLOP/s dense bf16 MFMA peak, plus the dominant kernel's own
+                  live-measured average duration (HIP events on the stream the kernel runs on),
+  `parity`        the HIP path's logits / loss / gradient errors against the CPU oracle on the benched configuration,
+  `cpu_baseline`  the CPU oracle timed on this host (the reported baseline, never the target),
+  `torch_baseline` stock PyTorch-ROCm (bf16 autocast, SDPA, fused AdamW) on the same synthetic step, for context.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 import torch
 import torch.distributed as dist
-import torch.nn.functional as F
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -29,8 +34,8 @@ sys.path.insert(0, REPO)
 GFLOP_PER_IMG = {"cls": 105.38, "mae": 58.16}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense bf16 MFMA / f32 MFMA
 PEAK_HBM_GBPS = 8000.0                         # MI355X_MICROARCH.md: HBM3E
-HBM_KERNELS = {}
 OVERLAP_ADAMW = os.environ.get("PM_OVERLAP_ADAMW", "1") != "0"  # A/B switch: AdamW beside the next forward
+WORKLOAD_NAME = {"cls": "ViT-B/16 classification fine-tune", "mae": "MAE pre-train ViT-B/16 mask 0.75"}
 
 
 def parse():
@@ -43,7 +48,15 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 cls / 256 mae)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-stats", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity block (CPU time)")
+    ap.add_argument("--no-mae", action="store_true", help="cls headline only (no MAE sub-record)")
+    ap.add_argument("--no-torch-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="SURVEY 8-d protocol in full for the CPU baseline (>=3 warm-up + >=10 timed steps at bs=8 AND bs=64, "
+                         "all cores and 8 threads): several minutes of CPU time")
+    ap.add_argument("--lr-every-step", action="store_true",
+                    help="change the learning rate before every step, as engine_pretrain.py:47-48 does (exercises the "
+                         "non-blocking hyper-parameter upload)")
     ap.add_argument("--input", choices=["resident", "host"], default="resident",
                     help="resident (the contract: batch already in HBM) or host: uint8 HWC frames in pinned host memory, "
                          "copied and normalised on a side stream each step (PCIe-inclusive rate, DESIGN.md)")
@@ -85,19 +98,31 @@ def make_batch(workload, batch, device, rank):
     return imgs, labels
 
 
-def make_step(workload, ddp, opt, imgs, labels):
+def make_step(workload, ddp, opt, imgs, labels, lr_every_step=False):
+    import ssl4polyp_amd as A
     pos_weight = torch.tensor(1.0, device=imgs.device)
+    base_lr = [g["lr"] for g in opt.param_groups]
+    counter = [0]
+
+    def touch_lr():
+        if lr_every_step:  # engine_pretrain.py:47-48: a new lr before every iteration
+            counter[0] += 1
+            f = 1.0 - 1e-4 * (counter[0] % 7)
+            for g, b in zip(opt.param_groups, base_lr):
+                g["lr"] = b * f
+
     if workload == "cls":
         def step(imgs=imgs, labels=labels):
+            touch_lr()
             opt.zero_grad(set_to_none=True)
             logits = ddp(imgs)
-            z = logits[:, 1] - logits[:, 0]                       # tc.py:3347-3359
-            loss = F.binary_cross_entropy_with_logits(z, labels.float(), pos_weight=pos_weight)  # tc.py:6090-6102
+            loss = A.supervised_loss(logits, labels, pos_weight=pos_weight)  # tc.py:3347-3374, 6090-6102 (one HIP launch)
             loss.backward()
             opt.step()
             return loss
     else:
         def step(imgs=imgs, labels=labels):
+            touch_lr()
             opt.zero_grad(set_to_none=True)
             loss, _, _ = ddp(imgs, mask_ratio=0.75)
             loss.backward()
@@ -107,93 +132,355 @@ def make_step(workload, ddp, opt, imgs, labels):
 
 
 def kernel_stats(model, step):
-    """Per-launch HIP-event timing of every GEMM of one step (events on the stream the kernels are launched on)."""
+    """Per-launch HIP-event timing of the GEMMs, LayerNorms and attention calls of one step (events recorded on the stream
+    each kernel is launched on)."""
     k = model._rt.k
-    orig = k.gemm
-    rec = []
+    orig = dict(gemm=k.gemm, lnf=k.layernorm_fwd, lnb=k.layernorm_bwd, af=k.attention_fwd, ab=k.attention_bwd)
+    rec, hbm, att = [], [], []
+    act_b = 2 if k.precision == "bf16" else 4
 
-    def timed(A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig(A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, **kw)
-        e1.record()
+    def ev2():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def gemm(A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, **kw):
+        e0, e1 = ev2()
+        e0.record(); orig["gemm"](A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, **kw); e1.record()
         rec.append((("tn" if akm else "n") + ("n" if bkm else "t"), M, N, K, e0, e1))
 
-    # the HBM-bound kernels of the path, timed the same way: algorithmic bytes / launch time against the HBM peak
-    hbm = []
-    orig_lnf, orig_lnb = k.layernorm_fwd, k.layernorm_bwd
-    act_b = 2 if model._rt.k.precision == "bf16" else 4
-
     def ln_fwd(x, gamma, beta, y, mean, rstd, M, D):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); orig_lnf(x, gamma, beta, y, mean, rstd, M, D); e1.record()
+        e0, e1 = ev2()
+        e0.record(); orig["lnf"](x, gamma, beta, y, mean, rstd, M, D); e1.record()
         hbm.append(("layernorm_fwd", M * D * (4 + act_b), e0, e1))
 
     def ln_bwd(dy, x, gamma, mean, rstd, dres, dx, dx_act, dgamma, dbeta, dcolsum, M, D):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); orig_lnb(dy, x, gamma, mean, rstd, dres, dx, dx_act, dgamma, dbeta, dcolsum, M, D); e1.record()
+        e0, e1 = ev2()
+        e0.record(); orig["lnb"](dy, x, gamma, mean, rstd, dres, dx, dx_act, dgamma, dbeta, dcolsum, M, D); e1.record()
         hbm.append(("layernorm_bwd", M * D * (act_b + 4 + 4 + 4 + act_b), e0, e1))
 
-    k.gemm, k.layernorm_fwd, k.layernorm_bwd = timed, ln_fwd, ln_bwd
+    def attn_fwd(qkv, out, lse, B, N, H, dh):
+        e0, e1 = ev2()
+        e0.record(); orig["af"](qkv, out, lse, B, N, H, dh); e1.record()
+        att.append(("attention_fwd", 4.0 * B * H * N * N * dh, e0, e1))
+
+    def attn_bwd(qkv, out, dout, lse, delta, dqkv, B, N, H, dh):
+        e0, e1 = ev2()
+        e0.record(); orig["ab"](qkv, out, dout, lse, delta, dqkv, B, N, H, dh); e1.record()
+        att.append(("attention_bwd", 10.0 * B * H * N * N * dh, e0, e1))
+
+    k.gemm, k.layernorm_fwd, k.layernorm_bwd, k.attention_fwd, k.attention_bwd = gemm, ln_fwd, ln_bwd, attn_fwd, attn_bwd
     try:
         for _ in range(3):
-            rec.clear()
-            hbm.clear()
+            rec.clear(); hbm.clear(); att.clear()
             step()
         torch.cuda.synchronize()
     finally:
-        k.gemm, k.layernorm_fwd, k.layernorm_bwd = orig, orig_lnf, orig_lnb
-    hb = {}
-    for name, nbytes, e0, e1 in hbm:
-        d = hb.setdefault(name, [0, 0.0, 0.0])
-        d[0] += 1
-        d[1] += e0.elapsed_time(e1) * 1e-3
-        d[2] += nbytes
-    global HBM_KERNELS
-    HBM_KERNELS = {n: {"launches": c, "avg_us": round(t / c * 1e6, 2), "GBps": round(b / t / 1e9, 1),
-                       "frac_of_hbm_peak": round(b / t / 1e9 / PEAK_HBM_GBPS, 3)} for n, (c, t, b) in hb.items()}
-    by = {}
-    for lay, M, N, K, e0, e1 in rec:
-        d = by.setdefault(lay, [0, 0.0, 0.0])
-        d[0] += 1
-        d[1] += e0.elapsed_time(e1) * 1e-3
-        d[2] += 2.0 * M * N * K
-    out = {}
-    for lay, (n, t, fl) in by.items():
-        out[lay] = {"launches": n, "avg_us": round(t / n * 1e6, 2), "tflops": round(fl / t / 1e12, 1)}
-    tot_t = sum(v[1] for v in by.values())
-    tot_f = sum(v[2] for v in by.values())
-    return out, tot_t, tot_f
+        k.gemm, k.layernorm_fwd, k.layernorm_bwd = orig["gemm"], orig["lnf"], orig["lnb"]
+        k.attention_fwd, k.attention_bwd = orig["af"], orig["ab"]
+
+    def fold(items, unit):
+        d = {}
+        for name, work, e0, e1 in items:
+            v = d.setdefault(name, [0, 0.0, 0.0])
+            v[0] += 1
+            v[1] += e0.elapsed_time(e1) * 1e-3
+            v[2] += work
+        out = {}
+        for n, (c, t, w) in d.items():
+            if unit == "GBps":
+                out[n] = {"launches": c, "avg_us": round(t / c * 1e6, 2), "GBps": round(w / t / 1e9, 1),
+                          "frac_of_hbm_peak": round(w / t / 1e9 / PEAK_HBM_GBPS, 3)}
+            else:
+                out[n] = {"launches": c, "avg_us": round(t / c * 1e6, 2), "tflops": round(w / t / 1e12, 1)}
+        return out
+
+    gem = fold([(lay, 2.0 * M * N * K, e0, e1) for lay, M, N, K, e0, e1 in rec], "tflops")
+    tot_t = sum(v["launches"] * v["avg_us"] for v in gem.values()) * 1e-6
+    return gem, fold(hbm, "GBps"), fold(att, "tflops"), tot_t
 
 
-def cpu_baseline(workload, steps):
-    """The CPU oracle (oracle/vit_mae_ref.py, fp32, torch CPU threads) on a bounded sample of the same workload:
-    bs=8 synthetic batch, reference step order (zero_grad -> fwd -> loss -> bwd -> AdamW)."""
+# ---------------------------------------------------------------------------------------------------------------------
+# the oracle legs (CPU): baseline timing and parity
+# ---------------------------------------------------------------------------------------------------------------------
+def physical_cores():
+    """(physical cores of the host from lscpu, CPUs this process may run on)."""
+    usable = len(os.sched_getaffinity(0))
+    try:
+        out = subprocess.run(["lscpu", "-p=core,socket"], capture_output=True, text=True, timeout=10).stdout
+        phys = len({ln for ln in out.splitlines() if ln and not ln.startswith("#")})
+    except Exception:
+        phys = 0
+    try:  # cgroup CPU quota of the box, if any
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            usable = min(usable, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return phys, usable
+
+
+def cpu_baseline(workload, full):
+    """The CPU oracle (oracle/vit_mae_ref.py, fp32, torch CPU threads) on a bounded sample of the same workload: synthetic
+    batch, reference step order (zero_grad -> fwd -> loss -> bwd -> AdamW), SURVEY 8-d protocol.  Headline figure: bs=8,
+    every usable core; also the 8-thread figure (comparable with the survey container) and one bs=64 point."""
     from oracle import vit_mae_ref as O
     cfg = O.VIT_BASE
-    B = 8
+    phys, usable = physical_cores()
     sd = O.generated_state_dict(cfg, seed=1, decoder=(workload == "mae"), n_class=2 if workload == "cls" else None)
     params = {n: v.clone().requires_grad_("pos_embed" not in n) for n, v in sd.items()}
     leaves = [p for p in params.values() if p.requires_grad]
     opt = torch.optim.AdamW(leaves, lr=1e-3, weight_decay=0.05)
-    imgs, labels, noise = O.generated_batch(cfg, B, seed=2)
+
+    def run(B, threads, warm, timed):
+        torch.set_num_threads(threads)
+        imgs, labels, noise = O.generated_batch(cfg, B, seed=2)
+
+        def one():
+            opt.zero_grad()
+            if workload == "cls":
+                loss = O.supervised_loss(O.vit_classify(params, imgs, cfg), labels, 1.0)
+            else:
+                loss = O.mae_forward(params, imgs, noise, cfg)[0]
+            loss.backward()
+            opt.step()
+
+        for _ in range(warm):
+            one()
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            one()
+        dt = time.perf_counter() - t0
+        return {"batch": B, "threads": threads, "warmup": warm, "timed_steps": timed, "images_per_sec": round(B * timed / dt, 3)}
+
+    prev = torch.get_num_threads()
+    try:
+        if full:
+            pts = [run(8, usable, 3, 10), run(8, min(8, usable), 3, 10), run(64, usable, 3, 10), run(64, min(8, usable), 3, 10)]
+        else:
+            pts = [run(8, usable, 3, 10), run(8, min(8, usable), 1, 3), run(64, usable, 1, 2)]
+    finally:
+        torch.set_num_threads(prev)
+    head = pts[0]
+    return {"value": head["images_per_sec"], "unit": "images/sec", "cores": usable, "kind": "port",
+            "host_physical_cores": phys, "points": pts,
+            "sample": f"{head['timed_steps']} timed steps (+{head['warmup']} warm-up) of the fp32 CPU oracle, {workload} ViT-B/16 "
+                      f"224^2, bs=8, {usable} threads = the CPUs this box grants the job (host: {phys} physical cores); "
+                      "`points` adds the 8-thread and the bs=64 figures (SURVEY 8-d); --cpu-full runs >=10 timed steps for each"}
+
+
+def parity_block(workload, model, imgs, labels, precision):
+    """The HIP path against the CPU oracle on the BENCHED configuration: the model's own weights and the benched batch go
+    through oracle/vit_mae_ref.py (fp32, CPU); errors as the tests define them (max-rel for logits / loss, rel-L2 for pred
+    and parameter gradients).  cls: forward + backward at the full batch; MAE: forward + loss at the full batch (its
+    backward is checked by tests/test_gpu_parity_large.py at B = 48, the CPU time of a B = 256 backward is minutes)."""
+    import ssl4polyp_amd as A
+    from oracle import vit_mae_ref as O
+    cfg = O.VIT_BASE
+    t0 = time.perf_counter()
+    _, usable = physical_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(min(usable, 32))
+    model._rt.wait_updates()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+
+    def rel(a, b):
+        a, b = a.double().cpu(), b.double().cpu()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+    def rel_l2(a, b):
+        a, b = a.double().cpu(), b.double().cpu()
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+    out = {"config": f"{WORKLOAD_NAME[workload]}, bs={imgs.shape[0]}, {precision}", "oracle": "oracle/vit_mae_ref.py fp32 CPU"}
+    try:
+        model.zero_grad(set_to_none=True)
+        if workload == "cls":
+            logits = model(imgs)
+            loss = A.supervised_loss(logits, labels, pos_weight=1.0)
+            loss.backward()
+            leaves = {n: v.clone().requires_grad_("pos_embed" not in n) for n, v in sd.items()}
+            lr = O.vit_classify(leaves, imgs.cpu(), cfg)
+            lo = O.supervised_loss(lr, labels.cpu(), 1.0)
+            lo.backward()
+            errs = {n: rel_l2(p.grad, leaves[n].grad) for n, p in model.named_parameters()
+                    if p.grad is not None and leaves[n].grad is not None and not n.endswith("attn.qkv.bias")}
+            worst = max(errs, key=errs.get)
+            out.update(logits_max_rel=rel(logits, lr.detach()), loss_rel=rel(loss, lo.detach()),
+                       grad_rel_l2_worst=errs[worst], grad_rel_l2_worst_name=worst,
+                       grad_rel_l2_median=sorted(errs.values())[len(errs) // 2], grads_compared=len(errs))
+        else:
+            g = torch.Generator(device=imgs.device).manual_seed(4321)
+            noise = torch.rand(imgs.shape[0], 196, device=imgs.device, generator=g)
+            with torch.no_grad():
+                loss, pred, mask = model(imgs, mask_ratio=0.75, noise=noise)
+                lo, pr, mr = O.mae_forward(sd, imgs.cpu(), noise.cpu(), cfg)
+            out.update(loss_rel=rel(loss, lo), pred_rel_l2=rel_l2(pred, pr), mask_equal=bool(torch.equal(mask.cpu(), mr)))
+        model.zero_grad(set_to_none=True)
+    finally:
+        torch.set_num_threads(prev)
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    out = {k: (float(f"{v:.3e}") if isinstance(v, float) and k != "seconds" else v) for k, v in out.items()}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stock PyTorch-ROCm on the same synthetic step (context only)
+# ---------------------------------------------------------------------------------------------------------------------
+def torch_baseline(device, batch, steps=10, warmup=3):
+    """ViT-B/16 classifier in plain torch.nn (same architecture), bf16 autocast, F.scaled_dot_product_attention, fused
+    torch.optim.AdamW, BCE-with-logits: what a user gets from the library path on this box.  Never the target."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    class Blk(nn.Module):
+        def __init__(s, D=768, H=12):
+            super().__init__()
+            s.n1, s.n2 = nn.LayerNorm(D, eps=1e-6), nn.LayerNorm(D, eps=1e-6)
+            s.qkv, s.proj, s.fc1, s.fc2, s.H = nn.Linear(D, 3 * D), nn.Linear(D, D), nn.Linear(D, 4 * D), nn.Linear(4 * D, D), H
+
+        def forward(s, x):
+            B, N, D = x.shape
+            q, k, v = s.qkv(s.n1(x)).reshape(B, N, 3, s.H, D // s.H).permute(2, 0, 3, 1, 4)
+            x = x + s.proj(F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, D))
+            return x + s.fc2(F.gelu(s.fc1(s.n2(x))))
+
+    class Vit(nn.Module):
+        def __init__(s, D=768):
+            super().__init__()
+            s.pe = nn.Conv2d(3, D, 16, 16)
+            s.cls, s.pos = nn.Parameter(torch.zeros(1, 1, D)), nn.Parameter(torch.zeros(1, 197, D))
+            s.blocks = nn.Sequential(*[Blk() for _ in range(12)])
+            s.norm, s.head = nn.LayerNorm(D, eps=1e-6), nn.Linear(D, 2)
+
+        def forward(s, x):
+            x = s.pe(x).flatten(2).transpose(1, 2)
+            x = torch.cat((s.cls.expand(x.shape[0], -1, -1), x), 1) + s.pos
+            return s.head(s.norm(s.blocks(x))[:, 0])
+
+    torch.manual_seed(0)
+    m = Vit().to(device)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.05, fused=True)
+    imgs, labels = make_batch("cls", batch, device, 0)
 
     def one():
-        opt.zero_grad()
-        if workload == "cls":
-            loss = O.supervised_loss(O.vit_classify(params, imgs, cfg), labels, 1.0)
-        else:
-            loss = O.mae_forward(params, imgs, noise, cfg)[0]
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            z = m(imgs)
+        loss = F.binary_cross_entropy_with_logits((z[:, 1] - z[:, 0]).float(), labels.float())
         loss.backward()
         opt.step()
 
-    one()
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"value": round(B * steps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} timed steps (+1 warm-up) of the fp32 CPU oracle, {workload} ViT-B/16 224^2, bs={B}"}
+    del m, opt
+    torch.cuda.empty_cache()
+    return {"value": round(batch * steps / dt, 1), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
+            "what": f"stock PyTorch {torch.__version__} (rocBLAS/hipBLASLt GEMMs, SDPA attention, bf16 autocast, fused AdamW), "
+                    f"same ViT-B/16 fine-tune step, bs={batch}, {steps} timed steps; context only, not the target"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_workload(args, workload, batch, device, world, rank, headline):
+    """Build, warm up, time exactly args.steps steps (barrier + synchronize on both sides, max over ranks)."""
+    model, ddp, opt = build(workload, args.precision, device, world, batch)
+    imgs, labels = make_batch(workload, batch, device, rank)
+    eager_step = make_step(workload, ddp, opt, imgs, labels, args.lr_every_step)
+    use_graph = args.graph == "on"  # auto: eager (measured faster: graph replay serialises the wgrad side stream)
+    if use_graph:
+        from ssl4polyp_amd.graph import GraphedStep
+        graphed = GraphedStep(eager_step, opt, warmup=3)  # capture failures are fatal: no silent eager fallback
+        step = graphed.replay
+    else:
+        step = eager_step
+
+    host_pool, host_gen = [], torch.Generator().manual_seed(1234 + rank)
+    host_input = args.input == "host" and headline
+    if host_input:  # four decoded batches in pinned host memory, built outside the timed region
+        host_pool = [(torch.randint(0, 256, (batch, 224, 224, 3), dtype=torch.uint8, generator=host_gen).pin_memory(),
+                      (torch.rand(batch, generator=host_gen) < 0.5).long().pin_memory()) for _ in range(4)]
+
+    def host_feed(n):
+        # uint8 HWC frames + labels in pinned host memory -> DevicePrefetcher (H2D + flips + ToTensor + Normalize)
+        from ssl4polyp_amd.data import DevicePrefetcher
+        return DevicePrefetcher([host_pool[i % 4] for i in range(n)], device, flip_p=0.5, generator=host_gen)
+
+    if host_input:
+        if use_graph:
+            sys.exit("--input host feeds a new batch every step: use eager launch")
+        for im, lb in host_feed(args.warmup):
+            step(im, lb)
+    else:
+        for _ in range(args.warmup):
+            step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if host_input:
+        for im, lb in host_feed(args.steps):
+            loss = step(im, lb)
+    else:
+        for _ in range(args.steps):
+            loss = step()
+    t_enq = time.perf_counter() - t0  # the host has enqueued every step; the device may still be running
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_val = float(loss.detach())
+    if not (loss_val == loss_val):
+        sys.exit("non-finite loss in the timed region")
+    rec = None
+    if rank == 0:
+        ips = batch * world * args.steps / dt
+        per_gpu_tflops = ips / world * GFLOP_PER_IMG[workload] / 1e3
+        peak = PEAK_TFLOPS[args.precision]
+        roof = {"bound": "mfma", "achieved": round(per_gpu_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(per_gpu_tflops / peak, 4), "traffic": None,
+                "basis": f"{GFLOP_PER_IMG[workload]} algorithmic GFLOP/img/step x img/s/GPU (BASELINE.md §3)"}
+        if not args.no_kernel_stats:
+            ks, hb, at, gt = kernel_stats(model, eager_step)
+            dom = max(ks.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])
+            roof["kernel"] = {"name": f"gemm_kernel<{args.precision},{dom[0]}>", **dom[1],
+                              "frac": round(dom[1]["tflops"] / peak, 4),
+                              "note": "in-step launch times: launches of the two forward chains / of the dgrad and "
+                                      "weight-gradient streams overlap, so each shares the CUs (stand-alone rates: DESIGN.md)"}
+            try:  # PMC traffic of the dominant kernel, from the committed rocprofv3 --pmc passes (profiles/)
+                with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as fh:
+                    t = json.load(fh).get(workload, {}).get(dom[0])
+                if t and args.precision == "bf16" and batch == (64 if workload == "cls" else 256):
+                    roof["traffic"] = {"MB_per_launch": t["MB_per_launch"], "algorithmic_MB_per_launch": t["algorithmic_MB_per_launch"],
+                                       "source": t["source"]}
+            except (OSError, ValueError):
+                pass
+            roof["gemm_by_layout"] = ks
+            roof["attention"] = at          # algorithmic 4 (fwd) / 10 (bwd) N^2 dh FLOP per head over the launch time
+            roof["hbm_kernels"] = hb        # in-step (beside the weight-gradient stream), algorithmic bytes / time
+            roof["gemm_share_of_step"] = round(gt / (dt / args.steps), 3)
+        rec = {"value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+               "config": {"workload": WORKLOAD_NAME[workload] + f", bs={batch}/GPU, 224^2, AdamW, random init",
+                          "global_batch": batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
+                          "launch": "hipGraph replay" if use_graph else "eager",
+                          "lr_schedule": "new lr every step" if args.lr_every_step else "constant"},
+               "roofline": roof}
+        if world == 1 and not args.no_parity:
+            rec["parity"] = parity_block(workload, model, imgs, labels, args.precision)
+    del model, ddp, opt, eager_step, step
+    torch.cuda.empty_cache()
+    return rec
 
 
 def main():
@@ -220,98 +507,34 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
     batch = args.batch or (64 if args.workload == "cls" else 256)
-    model, ddp, opt = build(args.workload, args.precision, device, world, batch)
-    imgs, labels = make_batch(args.workload, batch, device, rank)
-    eager_step = make_step(args.workload, ddp, opt, imgs, labels)
-    use_graph = args.graph == "on"  # auto: eager (measured faster: graph replay serialises the wgrad side stream)
-    if use_graph:
-        from ssl4polyp_amd.graph import GraphedStep
-        graphed = GraphedStep(eager_step, opt, warmup=3)  # capture failures are fatal: no silent eager fallback
-        step = graphed.replay
-    else:
-        step = eager_step
-
-    host_pool, host_gen = [], torch.Generator().manual_seed(1234 + rank)
-    if args.input == "host":  # four decoded batches in pinned host memory, built outside the timed region
-        host_pool = [(torch.randint(0, 256, (batch, 224, 224, 3), dtype=torch.uint8, generator=host_gen).pin_memory(),
-                      (torch.rand(batch, generator=host_gen) < 0.5).long().pin_memory()) for _ in range(4)]
-
-    def host_feed(n):
-        # uint8 HWC frames + labels in pinned host memory -> DevicePrefetcher (H2D + flips + ToTensor + Normalize)
-        from ssl4polyp_amd.data import DevicePrefetcher
-        return DevicePrefetcher([host_pool[i % 4] for i in range(n)], device, flip_p=0.5, generator=host_gen)
-
-    if args.input == "host":
-        if use_graph:
-            sys.exit("--input host feeds a new batch every step: use eager launch")
-        for im, lb in host_feed(args.warmup):
-            step(im, lb)
-    else:
-        for _ in range(args.warmup):
-            step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if args.input == "host":
-        for im, lb in host_feed(args.steps):
-            loss = step(im, lb)
-    else:
-        for _ in range(args.steps):
-            loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    loss_val = float(loss.detach())
-    if not (loss_val == loss_val):
-        sys.exit("non-finite loss in the timed region")
+    head = run_workload(args, args.workload, batch, device, world, rank, True)
+    sub = None
+    if args.workload == "cls" and not args.no_mae and not args.batch and args.input == "resident":
+        # BASELINE.json metric: "(MAE pretrain + cls finetune)": configs[2], same process, same protocol
+        sub = run_workload(args, "mae", 256, device, world, rank, False)
 
     if rank == 0:
-        ips = batch * world * args.steps / dt
-        per_gpu_tflops = ips / world * GFLOP_PER_IMG[args.workload] / 1e3
-        peak = PEAK_TFLOPS[args.precision]
-        roof = {"bound": "mfma", "achieved": round(per_gpu_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(per_gpu_tflops / peak, 4), "traffic": None,
-                "basis": f"{GFLOP_PER_IMG[args.workload]} algorithmic GFLOP/img/step x img/s/GPU (BASELINE.md §3)"}
-        if not args.no_kernel_stats:
-            ks, gt, gf = kernel_stats(model, eager_step)
-            dom = max(ks.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])
-            roof["kernel"] = {"name": f"gemm_kernel<{args.precision},{dom[0]}>", **dom[1],
-                              "frac": round(dom[1]["tflops"] / peak, 4),
-                              "note": "in-step launch times: launches of the two forward chains / of the dgrad and "
-                                      "weight-gradient streams overlap, so each shares the CUs (stand-alone rates: DESIGN.md)"}
-            try:  # PMC traffic of the dominant kernel, from the committed rocprofv3 --pmc passes (profiles/)
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as fh:
-                    t = json.load(fh).get(args.workload, {}).get(dom[0])
-                if t and args.precision == "bf16" and batch == 64:
-                    roof["traffic"] = {"MB_per_launch": t["MB_per_launch"], "algorithmic_MB_per_launch": t["algorithmic_MB_per_launch"],
-                                       "source": t["source"]}
-            except (OSError, ValueError):
-                pass
-            roof["gemm_by_layout"] = ks
-            roof["hbm_kernels"] = HBM_KERNELS  # in-step (beside the weight-gradient stream), algorithmic bytes / time
-            roof["gemm_share_of_step"] = round(gt / (dt / args.steps), 3)
         out = {
             "metric": "training-step images/sec/node, ViT-B/16 224^2 (" + ("cls fine-tune" if args.workload == "cls" else "MAE pre-train") + ")",
-            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "value": head["value"], "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic" if args.input == "resident" else "synthetic uint8 frames in pinned host memory (PCIe-inclusive)",
-            "config": {"workload": ("ViT-B/16 classification fine-tune" if args.workload == "cls" else
-                                    "MAE pre-train ViT-B/16 mask 0.75") + f", bs={batch}/GPU, 224^2, AdamW, random init",
-                       "global_batch": batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
-                       "launch": "hipGraph replay" if use_graph else "eager"},
-            "roofline": roof,
+            "config": head["config"], "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
+            "roofline": head["roofline"],
         }
+        if "parity" in head:
+            out["parity"] = head["parity"]
+        if sub is not None:
+            out["mae"] = {"metric": "training-step images/sec/node, ViT-B/16 224^2 (MAE pre-train)", "steps": args.steps,
+                          "warmup": args.warmup, **sub}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_full)
+        if world == 1 and not args.no_torch_baseline and args.precision == "bf16":
+            try:
+                out["torch_baseline"] = torch_baseline(device, 64)
+            except Exception as e:  # context only: never fail the bench line over it
+                out["torch_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

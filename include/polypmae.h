@@ -77,6 +77,20 @@ int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, long ldb, i
                const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
                int M, int N, int K, void* workspace, size_t ws_bytes, void* stream);
 
+/* pm_gemm_ws with per-call options (no process-wide tuning state):
+ *   max_blocks: workgroups a split-K weight-gradient GEMM (both operands k-major) spreads over; 0 = 256 = the whole
+ *               chip (fastest alone).  A caller that runs weight gradients on a second stream beside the dgrad chain
+ *               passes ~128 so that the chain keeps half of the CUs (the training engine does: +4.5 % step rate).
+ *   variant:    0 = the dispatcher's heuristics; otherwise forces one kernel variant (tuning scripts and tests; the
+ *               values are listed in pm_gemm.hip and are not stable across ABI versions). */
+typedef struct pm_gemm_opts {
+  int max_blocks;
+  int variant;
+} pm_gemm_opts;
+int pm_gemm_ex(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
+               const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
+               int M, int N, int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, void* stream);
+
 /* pm_gemm that also accumulates the column sums of the stored result: colsum[n] += sum_m C[m][n] (f32 [N]) -- the bias
  * gradient of the Linear whose output gradient C is (reference: autograd of nn.Linear, e.g. Mlp.fc1.bias.grad from the
  * dGELU dgrad).  Fused into the epilogue where the kernel in use supports it (act-typed C of the large-tile kernel;
@@ -159,16 +173,41 @@ int pm_cast(const float* src, void* dst, int dst_dtype, long n, void* stream);
 int pm_preprocess_u8(const unsigned char* src, const unsigned char* flip_flags, float* dst, int B, int H, int W,
                      float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
 
-/* Classifier head on the cls rows (models.py:209,216-221 + tc.py:3347-3374): final LayerNorm of row 0 of each
- * sample, Linear(D -> n_class) in f32.  x f32 [B, N, D]. */
+/* Top of the fine-tune forward (models.py:127,134-139 / 209,216-221): final LayerNorm, token selection, lin_head.
+ *   pool = 0 (out_token "cls"):     feat[b] = LN(x[b, 0])                 (only row 0 is normalised)
+ *   pool = 1 (out_token "spatial"): feat[b] = mean_{n >= 1} LN(x[b, n])   (x[:, 1:].mean(1))
+ *   logits = feat W^T + bias when W != NULL (head=True); W == NULL returns the features only (head=False).
+ * x f32 [B, N, D]; feat f32 [B, D]; mean / rstd f32 [B] (pool 0) or [B, N] (pool 1, row 0 unused); xhat_mean f32 [B, D]
+ * (pool 1 only: the pooled normalised rows, saved for backward); logits f32 [B, n_class].  D <= 1024. */
+int pm_vit_head_fwd(const float* x, int N, int pool, const float* gamma, const float* beta, const float* W,
+                    const float* bias, float* feat, float* xhat_mean, float* mean, float* rstd, float* logits, int B, int D,
+                    int n_class, float eps, void* stream);
+/* Backward.  Gradient source: dlogits f32 [B, n_class] (with W), or dfeat f32 [B, D] (head=False; then dlogits / W / dW /
+ * dbias are unused).  dx f32 [B,N,D] is fully written (rows that do not reach the feature get zeros) together with its
+ * act-typed copy dx_act (optional); dx == NULL = frozen backbone, nothing below is needed.  dW / dbias / dgamma / dbeta
+ * (+=, each optional) are summed over the batch in a fixed order. */
+int pm_vit_head_bwd(const float* dlogits, const float* dfeat, const float* x, int N, int pool, const float* gamma,
+                    const float* W, const float* feat, const float* xhat_mean, const float* mean, const float* rstd,
+                    float* dx, void* dx_act, int act_dtype, float* dW, float* dbias, float* dgamma, float* dbeta, int B,
+                    int D, int n_class, void* stream);
+/* The same with pool = 0 and a head (the shipped configuration: utils/__init__.py:29,52 default out_token "cls"). */
 int pm_cls_head_fwd(const float* x, int N, const float* gamma, const float* beta, const float* W, const float* bias,
                     float* xn, float* mean, float* rstd, float* logits, int B, int D, int n_class, float eps,
                     void* stream);
-/* Backward: dx f32 [B,N,D] fully written (zeros except row 0; NULL = frozen backbone, not needed);
- * dW/dbias/dgamma/dbeta (+=). */
 int pm_cls_head_bwd(const float* dlogits, const float* x, int N, const float* gamma, const float* W, const float* xn,
                     const float* mean, const float* rstd, float* dx, void* dx_act, int act_dtype, float* dW,
                     float* dbias, float* dgamma, float* dbeta, int B, int D, int n_class, void* stream);
+
+/* Supervised loss of the fine-tune loop on the logits (train_classification.py:3347-3374 _compute_supervised_loss,
+ * 6086-6104 loss construction), value and gradient in one launch:
+ *   n_class == 2 ("binary_bce"): z = l[:,1] - l[:,0]; BCEWithLogitsLoss(pos_weight)(z, y), mean over the batch;
+ *                                pos_weight: f32 DEVICE scalar or NULL (= 1)
+ *   n_class  > 2: CrossEntropyLoss(weight = class_weights f32 [n_class] or NULL), weighted mean.
+ * targets int64 [B]; loss f32 [1]; dlogits f32 [B, n_class] = d loss / d logits.  One block, fixed summation order. */
+int pm_supervised_loss_fwd(const float* logits, const long long* targets, const float* pos_weight,
+                           const float* class_weights, float* loss, float* dlogits, int B, int n_class, void* stream);
+/* out[i] = x[i] * scale[0] (scale: f32 device scalar) -- chains an upstream d loss into the saved dlogits. */
+int pm_scale(const float* x, const float* scale, float* out, long n, void* stream);
 
 /* Fused multi-tensor AdamW over one flat f32 parameter range (torch.optim.AdamW semantics,
  * tc.py:5766-5768 / main_pretrain.py:218) that also refreshes the act-typed shadow copy used by the GEMMs.
@@ -188,13 +227,14 @@ int pm_adamw_dev(float* p, const float* g, float* m, float* v, void* shadow, int
  * (the device-side counterpart of tc.py:1437-1454 _compute_grad_norm and misc.py:387-400 detect_grad_anomalies). */
 int pm_grad_stats(const float* g, long n, float* out, void* stream);
 
-/* Process-wide tuning knobs (no reference counterpart; defaults are the stand-alone optimum).  Returns the previous
- * value, or PM_EINVAL for an unknown knob / out-of-range value.
- *   PM_TUNE_WGRAD_BLOCKS: workgroups a split-K weight-gradient GEMM (both operands k-major) spreads over.  256 = the
- *     whole chip (fastest alone); a caller that runs weight gradients on a second stream beside the dgrad chain sets
- *     ~128 so that the chain keeps half of the CUs (the training engine does: +4.5 % step rate). */
-enum { PM_TUNE_WGRAD_BLOCKS = 1 };
-int pm_tune(int knob, int value);
+/* Scratch sizes.  Every workspace is caller-owned; these return the byte count that enables the deterministic
+ * (two-stage, fixed-order) form of the op for the given shape, 0 when the op needs none.
+ *   pm_gemm_workspace_bytes: the split-K slabs pm_gemm_ws / pm_gemm_ex would use for this GEMM under `opts`.
+ *   pm_workspace_bytes(kind, M, N): PM_WS_LAYERNORM_BWD (M rows, N = D), PM_WS_COLSUM (M x N matrix),
+ *   PM_WS_GEMM_COLSUM (pm_gemm_colsum of an M x N result), PM_WS_UNSHUFFLE_BWD (N = D). */
+enum pm_ws_kind { PM_WS_LAYERNORM_BWD = 1, PM_WS_COLSUM = 2, PM_WS_GEMM_COLSUM = 3, PM_WS_UNSHUFFLE_BWD = 4 };
+size_t pm_gemm_workspace_bytes(int a_kmajor, int b_kmajor, int in_dtype, int M, int N, int K, const pm_gemm_opts* opts);
+size_t pm_workspace_bytes(int kind, int M, int N);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ssl4polyp_amd.engine import Kernels
 from ssl4polyp_amd._lib import EPI_STORE, EPI_RESIDUAL, EPI_GELU, EPI_DGELU
-k = Kernels("bf16"); k.lib.pm_debug_gemm_config.argtypes = [ctypes.c_int]
+k = Kernels("bf16")
 dev="cuda"; M=int(os.environ.get("M", 12608)); D=int(os.environ.get("D", 768)); H=4*D; bf=torch.bfloat16
 CFGS = [int(c) for c in os.environ.get("CFGS", "0,16,17,18,19,20,21").split(",")]
 def t(*s, dt=bf): return (torch.randn(*s, device=dev) * 0.5).to(dt)
@@ -20,14 +20,14 @@ cases = [("qkv", lambda: k.linear_fwd(x, Wqkv, b3, o3, M, 3*D, D), 2*M*3*D*D),
          ("dqkv", lambda: k.linear_dgrad(x3, Wqkv, oD, M, 3*D, D), 2*M*3*D*D)]
 ref = x3.float() @ Wqkv.float(); ref2 = x.float() @ Wqkv.float().t() + b3
 for cfg in CFGS:
-    k.lib.pm_debug_gemm_config(cfg); oD.zero_(); o3.zero_()
+    k.gemm_variant = cfg; oD.zero_(); o3.zero_()
     k.linear_dgrad(x3, Wqkv, oD, M, 3*D, D); k.linear_fwd(x, Wqkv, b3, o3, M, 3*D, D)
     print(cfg, "rel err dgrad", ((oD.float()-ref).abs().max()/ref.abs().max()).item(), "fwd", ((o3.float()-ref2).abs().max()/ref2.abs().max()).item())
 for rnd in range(2):
   for name, fn, fl in cases:
     out=[]
     for cfg in CFGS:
-        k.lib.pm_debug_gemm_config(cfg)
+        k.gemm_variant = cfg
         for _ in range(3): fn()
         torch.cuda.synchronize(); e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -35,4 +35,4 @@ for rnd in range(2):
         e1.record(); torch.cuda.synchronize(); us=e0.elapsed_time(e1)*1e3/20
         out.append(f"c{cfg}:{us:6.1f}us {fl/us/1e6:4.0f}TF")
     print(f"{name:5s} "+"  ".join(out))
-k.lib.pm_debug_gemm_config(0)
+k.gemm_variant = 0

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ssl4polyp_amd.engine import Kernels
 import ctypes
-k = Kernels("bf16"); k.lib.pm_debug_gemm_config.argtypes = [ctypes.c_int]; k.lib.pm_debug_gemm_config((int(os.environ.get("WV", 0)) << 6) | (int(os.environ.get("HDM", 0)) << 8)); dev="cuda"; M=12608; D=768; H=3072; bf=torch.bfloat16
+k = Kernels("bf16"); k.gemm_variant = (int(os.environ.get("WV", 0)) << 6) | (int(os.environ.get("HDM", 0)) << 8); k.WGRAD_BLOCKS = int(os.environ.get("WB", 256)); dev="cuda"; M=12608; D=768; H=3072; bf=torch.bfloat16
 def t(*s, dt=bf): return (torch.randn(*s, device=dev) * 0.5).to(dt)
 xD, x3, xH = t(M, D), t(M, 3*D), t(M, H)
 gq, gp, g1, g2 = (torch.empty(n, kk, device=dev) for n, kk in ((3*D, D), (D, D), (H, D), (D, H)))

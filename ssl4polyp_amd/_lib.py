@@ -23,6 +23,7 @@ SIGNATURES = {
     "pm_layernorm_bwd": [P, I, P, L, P, P, P, P, L, P, L, P, I, P, P, P, I, I, P, ctypes.c_size_t, P],
     "pm_gemm": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P],
     "pm_gemm_ws": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P],
+    "pm_gemm_ex": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P, P],
     "pm_gemm_colsum": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, P, I, I, I, P, ctypes.c_size_t, P],
     "pm_attention_fwd": [P, P, P, I, I, I, I, I, P],
     "pm_attention_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
@@ -39,17 +40,27 @@ SIGNATURES = {
     "pm_mae_loss_bwd": [P, P, L, I, P, P, P, P, I, I, I, I, I, I, P],
     "pm_cast": [P, P, I, L, P],
     "pm_preprocess_u8": [P, P, P, I, I, I, F, F, F, F, F, F, P],
+    "pm_vit_head_fwd": [P, I, I, P, P, P, P, P, P, P, P, P, I, I, I, F, P],
+    "pm_vit_head_bwd": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, P, P, P, P, I, I, I, P],
+    "pm_supervised_loss_fwd": [P, P, P, P, P, P, I, I, P],
+    "pm_scale": [P, P, P, L, P],
     "pm_cls_head_fwd": [P, I, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "pm_cls_head_bwd": [P, P, I, P, P, P, P, P, P, P, I, P, P, P, P, I, I, I, P],
     "pm_adamw": [P, P, P, P, P, I, L, F, F, F, F, F, I, F, P],
     "pm_adamw_tick": [P, I, P],
     "pm_adamw_dev": [P, P, P, P, P, I, L, P, P],
     "pm_grad_stats": [P, L, P, P],
-    "pm_tune": [I, I],
 }
 
-TUNE_WGRAD_BLOCKS = 1
-ABI_VERSION = 2  # pm_abi_version() of the library these signatures describe
+ABI_VERSION = 3  # pm_abi_version() of the library these signatures describe
+
+WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4
+
+
+class GemmOpts(ctypes.Structure):
+    """pm_gemm_opts of include/polypmae.h."""
+    _fields_ = [("max_blocks", c_int), ("variant", c_int)]
+
 
 _lib = None
 
@@ -75,6 +86,10 @@ def load():
     if lib.pm_abi_version() != ABI_VERSION:  # a stale build would be called with the wrong argument lists
         raise PolypMaeError(f"{LIB_PATH} has ABI version {lib.pm_abi_version()}, this package binds version {ABI_VERSION}: "
                             "rebuild with `python -c 'import __graft_entry__ as g; g.build(force=True)'`")
+    lib.pm_gemm_workspace_bytes.restype = ctypes.c_size_t
+    lib.pm_gemm_workspace_bytes.argtypes = [I, I, I, I, I, I, P]
+    lib.pm_workspace_bytes.restype = ctypes.c_size_t
+    lib.pm_workspace_bytes.argtypes = [I, I, I]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = c_int

@@ -1152,16 +1152,13 @@ int launch_glds(const GemmArgs& a, int xk, int wk, hipStream_t s) {
   return pm_check_launch();
 }
 
-int g_wgrad_blocks = 256;  // pm_tune(PM_TUNE_WGRAD_BLOCKS)
-
-// pm_gemm_colsum -> pm_gemm_ws hand-off: the dispatcher fuses the column sums into the register epilogue of the
+// pm_gemm_colsum -> dispatcher hand-off: the dispatcher fuses the column sums into the register epilogue of the
 // large-tile kernel when it picks that kernel (and the partial rows fit), and reports how many partial rows it wrote.
 struct ColsumRequest {
   float* partials = nullptr;
   size_t capacity = 0;  // bytes
   int rows = 0;         // out: partial rows written (0 = not fused)
 };
-thread_local ColsumRequest g_cs_req;
 
 // out[n] += sum over the partial rows, fixed order
 __global__ __launch_bounds__(1024) void gemm_colsum_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out,
@@ -1178,29 +1175,92 @@ __global__ __launch_bounds__(1024) void gemm_colsum_reduce_kernel(const float* _
     out[n] += t;
   }
 }
-int g_force_cfg = 0;  // tuning hook (not part of the ABI): 0 auto, 1 = 128x128 kernels only, 2 = 256x128, 3 = 256x256
+// Split-K plan of a weight-gradient GEMM on the ring kernel (shared by the dispatcher and pm_gemm_workspace_bytes).
+// 256x256 tiles (twice the MFMAs per barrier) from 2x2 tiles up: ViT-B qkv / fc1 / fc2 gradients 74 us vs 83 with
+// 256x128; the MAE decoder's 512-wide gradients (K = 50 432 tokens) +2.8 % step rate; neutral for 768x768.
+// Variant bits 6-7: 1 = force 256x128, 2 = force 256x256, 3 = software-pipelined 256x256 (slower: tr reads).
+struct WgradPlan {
+  int wv;     // tile variant (1: 256x128, 2: 256x256, 3: software-pipelined 256x256)
+  int split;  // k-slices (each writes an f32 slab when > 1)
+};
+inline WgradPlan plan_wgrad(int M, int N, int K, int force_cfg, int wgrad_blocks, size_t ws_bytes) {
+  WgradPlan p;
+  p.wv = (force_cfg >> 6) & 3;
+  if (p.wv == 0) p.wv = ((M + 255) / 256) * ((N + 255) / 256) >= 4 ? 2 : 1;
+  const int bn3 = p.wv >= 2 ? 256 : 128;
+  const int t3 = ((M + 255) / 256) * ((N + bn3 - 1) / bn3);
+  const int nk3 = K / V3_KE;
+  int split = wgrad_blocks / t3;
+  if (split > nk3 / 16) split = nk3 / 16;
+  if (split > 16) split = 16;
+  if (split < 1) split = 1;
+  while (split > 1 && (size_t)split * M * N * sizeof(float) > ws_bytes) --split;
+  p.split = split;
+  return p;
+}
+inline bool wgrad_ring_shape(int in_dtype, int a_kmajor, int b_kmajor, int M, int N, int K) {
+  return in_dtype == PM_BF16 && a_kmajor && b_kmajor && (K % V3_KE) == 0 && K >= 2048 && M >= 256 && N >= 128;
+}
+
+int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
+                  const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid, int M, int N,
+                  int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, ColsumRequest* cs_req, void* stream);
 
 }  // namespace
 
-extern "C" void pm_debug_gemm_config(int cfg) { g_force_cfg = cfg; }
-
-extern "C" int pm_tune(int knob, int value) {
-  if (knob == PM_TUNE_WGRAD_BLOCKS) {
-    if (value < 16 || value > 1024) return PM_EINVAL;
-    const int prev = g_wgrad_blocks;
-    g_wgrad_blocks = value;
-    return prev;
+extern "C" size_t pm_gemm_workspace_bytes(int a_kmajor, int b_kmajor, int in_dtype, int M, int N, int K,
+                                          const pm_gemm_opts* opts) {
+  if (M <= 0 || N <= 0 || K <= 0 || !(a_kmajor && b_kmajor)) return 0;  // only the split-K weight gradients use scratch
+  int blocks = (opts && opts->max_blocks > 0) ? opts->max_blocks : 256;
+  blocks = blocks < 16 ? 16 : (blocks > 1024 ? 1024 : blocks);
+  const int variant = opts ? opts->variant : 0;
+  if (wgrad_ring_shape(in_dtype, a_kmajor, b_kmajor, M, N, K) && (variant & 63) != 1) {
+    const WgradPlan p = plan_wgrad(M, N, K, variant, blocks, (size_t)-1);
+    return p.split > 1 ? (size_t)p.split * M * N * sizeof(float) : 0;
   }
-  return PM_EINVAL;
+  // 128x128 split-K path: up to 16 slabs
+  const int ke = in_dtype == PM_BF16 ? 64 : 32;
+  if (K % ke) return 0;
+  const int nk = K / ke, tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  if (tiles >= 256 || nk < 16) return 0;
+  int split = 512 / tiles;
+  if (split > nk / 8) split = nk / 8;
+  if (split > 16) split = 16;
+  return split > 1 ? (size_t)split * M * N * sizeof(float) : 0;
 }
+
 #ifdef PM_GEMM_STAMP
 namespace { unsigned long long* g_stamps = nullptr; }
 extern "C" void pm_debug_gemm_stamps(void* p) { g_stamps = reinterpret_cast<unsigned long long*>(p); }
 #endif
 
+extern "C" int pm_gemm_ex(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
+                          const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
+                          int M, int N, int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, void* stream) {
+  return gemm_dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, in_dtype, bias, C, ldc, c_dtype, epilogue, aux, resid, M, N, K,
+                       workspace, ws_bytes, opts, nullptr, stream);
+}
+
 extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
                           const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux,
                           const float* resid, int M, int N, int K, void* workspace, size_t ws_bytes, void* stream) {
+  return gemm_dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, in_dtype, bias, C, ldc, c_dtype, epilogue, aux, resid, M, N, K,
+                       workspace, ws_bytes, nullptr, nullptr, stream);
+}
+
+namespace {
+
+int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
+                  const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid, int M, int N,
+                  int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, ColsumRequest* cs_req, void* stream) {
+  // per-call options (no process-wide state): kernel variant override (tuning scripts, tests) and the number of
+  // workgroups a split-K weight gradient may spread over
+  const int force_cfg = opts ? opts->variant : 0;
+  int wgrad_blocks = (opts && opts->max_blocks > 0) ? opts->max_blocks : 256;
+  if (wgrad_blocks < 16) wgrad_blocks = 16;
+  if (wgrad_blocks > 1024) wgrad_blocks = 1024;
+  ColsumRequest cs_none;
+  ColsumRequest& cs = cs_req ? *cs_req : cs_none;
   if (!A || !B || !C) return PM_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return PM_ESHAPE;
   if (in_dtype != PM_BF16 && in_dtype != PM_F32) return PM_EINVAL;
@@ -1236,10 +1296,10 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
     return in_dtype == PM_BF16 ? launch_generic<__bf16>(a, a_kmajor, b_kmajor, s) : launch_generic<float>(a, a_kmajor, b_kmajor, s);
   }
   // large-tile ring kernel: bf16, X k-normal (forward and dgrad GEMMs), big M
-  if (in_dtype == PM_BF16 && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (g_force_cfg & 63) != 1) {
+  if (in_dtype == PM_BF16 && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (force_cfg & 63) != 1) {
     // Tile / pipeline choice, tuned on the ViT-B/16 shapes at M = 12608 (scratch/bench_gemm6.py).
     // pm_debug_gemm_config(cfg) forces one of the variants below (0 = the heuristics).
-    int cfg = g_force_cfg & 63;
+    int cfg = force_cfg & 63;
     if (cfg == 0) {
       // 256x256 ping-pong everywhere; LDS-staged epilogue for the wide act-typed outputs (qkv, fc1+GELU: whole
       // 128-B row segments per store), direct register epilogue for f32 residual outputs and the dgrads
@@ -1253,12 +1313,12 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
         if (epilogue == PM_EPI_RESIDUAL && !b_kmajor) cfg = cfg == 10 ? 26 : 25;
       }
     }
-    if ((cfg == 9 || cfg == 10) && g_cs_req.partials && c_dtype == PM_BF16 && (N & 7) == 0 && (ldc & 7) == 0 &&
+    if ((cfg == 9 || cfg == 10) && cs.partials && c_dtype == PM_BF16 && (N & 7) == 0 && (ldc & 7) == 0 &&
         (epilogue == PM_EPI_STORE || epilogue == PM_EPI_DGELU)) {
       const int rows = ((M + (cfg == 9 ? 255 : 191)) / (cfg == 9 ? 256 : 192)) * 2;  // tiles_m x WM
-      if ((size_t)rows * N * sizeof(float) <= g_cs_req.capacity) {
-        a.cs_partials = g_cs_req.partials;
-        g_cs_req.rows = rows;
+      if ((size_t)rows * N * sizeof(float) <= cs.capacity) {
+        a.cs_partials = cs.partials;
+        cs.rows = rows;
       }
     }
     switch (cfg) {
@@ -1282,21 +1342,12 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
   const bool splittable = workspace && !bias && c_dtype == PM_F32 && (epilogue == PM_EPI_STORE || epilogue == PM_EPI_ACCUM) &&
                           ldc == N;
   // large-K wgrad on the ping-pong ring kernel: 256x128 tiles, split so that tiles x splits ~ one block per CU
-  if (splittable && in_dtype == PM_BF16 && a_kmajor && b_kmajor && (K % V3_KE) == 0 && K >= 2048 && M >= 256 && N >= 128 &&
-      (g_force_cfg & 63) != 1) {
+  if (splittable && wgrad_ring_shape(in_dtype, a_kmajor, b_kmajor, M, N, K) && (force_cfg & 63) != 1) {
     // 256x256 tiles (twice the MFMAs per barrier) from 2x2 tiles up: ViT-B qkv / fc1 / fc2 gradients 74 us vs 83 with
     // 256x128; the MAE decoder's 512-wide gradients (K = 50 432 tokens) +2.8 % step rate; neutral for 768x768.
     // Tuning hook bits 6-7: 1 = force 256x128, 2 = force 256x256, 3 = software-pipelined 256x256 (slower: tr reads).
-    int wv = (g_force_cfg >> 6) & 3;
-    if (wv == 0) wv = ((M + 255) / 256) * ((N + 255) / 256) >= 4 ? 2 : 1;
-    const int bn3 = wv >= 2 ? 256 : 128;
-    const int t3 = ((M + 255) / 256) * ((N + bn3 - 1) / bn3);
-    const int nk3 = K / V3_KE;
-    int split = g_wgrad_blocks / t3;
-    if (split > nk3 / 16) split = nk3 / 16;
-    if (split > 16) split = 16;
-    if (split < 1) split = 1;
-    while (split > 1 && (size_t)split * M * N * sizeof(float) > ws_bytes) --split;
+    const WgradPlan plan = plan_wgrad(M, N, K, force_cfg, wgrad_blocks, ws_bytes);
+    const int wv = plan.wv, nk3 = K / V3_KE, split = plan.split;
     GemmArgs w = a;
     w.ksteps_split = (nk3 + split - 1) / split;
     w.split_k = (nk3 + w.ksteps_split - 1) / w.ksteps_split;
@@ -1340,18 +1391,19 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
   return in_dtype == PM_BF16 ? launch_glds<__bf16>(a, a_kmajor, b_kmajor, s) : launch_glds<float>(a, a_kmajor, b_kmajor, s);
 }
 
+}  // namespace
+
 extern "C" int pm_gemm_colsum(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
                               const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux,
                               const float* resid, float* colsum, int M, int N, int K, void* workspace, size_t ws_bytes,
                               void* stream) {
   if (!colsum) return PM_EINVAL;
-  g_cs_req.partials = reinterpret_cast<float*>(workspace);
-  g_cs_req.capacity = workspace ? ws_bytes : 0;
-  g_cs_req.rows = 0;
-  const int st = pm_gemm_ws(A, lda, a_kmajor, B, ldb, b_kmajor, in_dtype, bias, C, ldc, c_dtype, epilogue, aux, resid, M, N, K,
-                            nullptr, 0, stream);
-  const int rows = g_cs_req.rows;
-  g_cs_req = ColsumRequest{};
+  ColsumRequest req;
+  req.partials = reinterpret_cast<float*>(workspace);
+  req.capacity = workspace ? ws_bytes : 0;
+  const int st = gemm_dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, in_dtype, bias, C, ldc, c_dtype, epilogue, aux, resid, M, N, K,
+                               nullptr, 0, nullptr, &req, stream);
+  const int rows = req.rows;
   if (st) return st;
   if (rows > 0) {
     hipLaunchKernelGGL(gemm_colsum_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, pm_stream(stream),

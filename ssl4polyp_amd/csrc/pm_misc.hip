@@ -1,5 +1,5 @@
 // pm_misc.hip -- the HBM-bound kernels around the GEMMs: patch im2col (+ kept-patch gather), token
-// assembly (cls / pos-embed), bias-gradient column sums, casts, classifier head, fused AdamW.
+// assembly (cls / pos-embed), bias-gradient column sums, casts, fused AdamW (the classifier head: pm_head.hip).
 // Reference ops replaced are named per kernel.  All are streaming kernels: 16-B vector accesses,
 // one wave64 per token row where a row is the unit, grid capped and grid-strided.
 #include "pm_common.h"
@@ -176,161 +176,6 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256)
     store4<T>(dst + 4 * i, *reinterpret_cast<const f32x4*>(src + 4 * i));
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(nvec << 2) + threadIdx.x] = (T)src[(nvec << 2) + threadIdx.x];
-}
-
-// ---------------------------------------------------------------------------------------------
-// classifier head: LayerNorm of the cls row + Linear(D -> n_class), f32 throughout
-// ---------------------------------------------------------------------------------------------
-constexpr int kHeadVec = 4;  // D <= 1024
-__global__ __launch_bounds__(64) void cls_head_fwd_kernel(const float* __restrict__ x, long sample_stride,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ W, const float* __restrict__ bias,
-                                                          float* __restrict__ xn, float* __restrict__ mean_out,
-                                                          float* __restrict__ rstd_out, float* __restrict__ logits, int D,
-                                                          int n_class, float eps) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const float* xr = x + (long)b * sample_stride;
-  const int nvec = D >> 2;
-  f32x4 v[kHeadVec];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < kHeadVec; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nvec) {
-      v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    }
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < kHeadVec; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nvec) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float d = v[i][e] - mean;
-        q += d * d;
-      }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-  if (lane == 0) {
-    mean_out[b] = mean;
-    rstd_out[b] = rstd;
-  }
-#pragma unroll
-  for (int i = 0; i < kHeadVec; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nvec) {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c);
-      const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + 4 * c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
-      *reinterpret_cast<f32x4*>(xn + (long)b * D + 4 * c) = v[i];
-    }
-  }
-  for (int k = 0; k < n_class; ++k) {
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < kHeadVec; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvec) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)k * D + 4 * c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc += v[i][e] * w[e];
-      }
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) logits[(long)b * n_class + k] = acc + (bias ? bias[k] : 0.f);
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void cls_head_bwd_kernel(const float* __restrict__ dlogits, const float* __restrict__ x,
-                                                           int N, const float* __restrict__ gamma,
-                                                           const float* __restrict__ W, const float* __restrict__ xn,
-                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           float* __restrict__ dx, T* __restrict__ dx_act,
-                                                           float* __restrict__ dW, float* __restrict__ dbias,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int D,
-                                                           int n_class) {
-  __shared__ float s_red[2][4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long sample = (long)N * D;
-  const float* xr = x + (long)b * sample;
-  const float mu = mean[b], rs = rstd[b];
-  // each thread owns columns tid, tid+256, ...
-  float s1 = 0.f, s2 = 0.f;
-  for (int d = tid; d < D; d += 256) {
-    float g = 0.f;
-    for (int k = 0; k < n_class; ++k) g += dlogits[(long)b * n_class + k] * W[(long)k * D + d];
-    const float xh = (xr[d] - mu) * rs;
-    const float gg = g * gamma[d];
-    s1 += gg;
-    s2 += gg * xh;
-  }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  if (lane == 0) {
-    s_red[0][wave] = s1;
-    s_red[1][wave] = s2;
-  }
-  __syncthreads();
-  const float c1 = ((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3])) / (float)D;
-  const float c2 = ((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3])) / (float)D;
-  for (int d = tid; d < D; d += 256) {
-    float g = 0.f;
-    for (int k = 0; k < n_class; ++k) g += dlogits[(long)b * n_class + k] * W[(long)k * D + d];
-    const float xh = (xr[d] - mu) * rs;
-    const float o = rs * (g * gamma[d] - c1 - xh * c2);
-    if (dx) dx[(long)b * sample + d] = o;
-    if (dx_act) dx_act[(long)b * sample + d] = (T)o;
-  }
-  if (!dx) return;  // frozen backbone: nothing below the head needs a gradient
-  // zero the gradient of every non-cls token of this sample
-  const long rest = sample - D;
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  for (long i = tid; i < (rest >> 2); i += 256) {
-    *reinterpret_cast<f32x4*>(dx + (long)b * sample + D + 4 * i) = z;
-    if (dx_act) store4<T>(dx_act + (long)b * sample + D + 4 * i, z);
-  }
-}
-
-// Parameter gradients of the head (lin_head weight / bias, final-norm gamma / beta): one thread per column walks the
-// samples in order -- a fixed summation order instead of one float atomic per (sample, column), so the whole training
-// step is reproducible bit for bit (B * (n_class + 3) loads per thread: a few microseconds).
-__global__ __launch_bounds__(256) void cls_head_pgrad_kernel(const float* __restrict__ dlogits, const float* __restrict__ x,
-                                                             long sample_stride, const float* __restrict__ W,
-                                                             const float* __restrict__ xn, const float* __restrict__ mean,
-                                                             const float* __restrict__ rstd, float* __restrict__ dW,
-                                                             float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int B, int D, int n_class) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d < D) {
-    float sg = 0.f, sb = 0.f;
-    for (int b = 0; b < B; ++b) {
-      float g = 0.f;
-      for (int k = 0; k < n_class; ++k) g += dlogits[(long)b * n_class + k] * W[(long)k * D + d];
-      const float xh = (x[(long)b * sample_stride + d] - mean[b]) * rstd[b];
-      sg += g * xh;
-      sb += g;
-    }
-    if (dgamma) dgamma[d] += sg;
-    if (dbeta) dbeta[d] += sb;
-    if (dW) {
-      for (int k = 0; k < n_class; ++k) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dlogits[(long)b * n_class + k] * xn[(long)b * D + d];
-        dW[(long)k * D + d] += s;
-      }
-    }
-  }
-  if (dbias && blockIdx.x == 0 && threadIdx.x < n_class) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dlogits[(long)b * n_class + threadIdx.x];
-    dbias[threadIdx.x] += s;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -545,37 +390,6 @@ extern "C" int pm_cast(const float* src, void* dst, int dst_dtype, long n, void*
   return pm_check_launch();
 }
 
-extern "C" int pm_cls_head_fwd(const float* x, int N, const float* gamma, const float* beta, const float* W,
-                               const float* bias, float* xn, float* mean, float* rstd, float* logits, int B, int D,
-                               int n_class, float eps, void* stream) {
-  if (!x || !gamma || !beta || !W || !xn || !mean || !rstd || !logits) return PM_EINVAL;
-  if (B <= 0 || N <= 0 || D <= 0 || D > 1024 || (D & 3) || n_class <= 0) return PM_ESHAPE;
-  hipLaunchKernelGGL(cls_head_fwd_kernel, dim3(B), dim3(64), 0, pm_stream(stream), x, (long)N * D, gamma, beta, W, bias, xn,
-                     mean, rstd, logits, D, n_class, eps);
-  return pm_check_launch();
-}
-
-extern "C" int pm_cls_head_bwd(const float* dlogits, const float* x, int N, const float* gamma, const float* W,
-                               const float* xn, const float* mean, const float* rstd, float* dx, void* dx_act,
-                               int act_dtype, float* dW, float* dbias, float* dgamma, float* dbeta, int B, int D,
-                               int n_class, void* stream) {
-  if (!dlogits || !x || !gamma || !W || !xn || !mean || !rstd) return PM_EINVAL;
-  if (!dx && dx_act) return PM_EINVAL;
-  if (B <= 0 || N <= 0 || D <= 0 || (D & 3) || n_class <= 0 || n_class > 256) return PM_ESHAPE;
-  if (act_dtype == PM_BF16)
-    hipLaunchKernelGGL(cls_head_bwd_kernel<__bf16>, dim3(B), dim3(256), 0, pm_stream(stream), dlogits, x, N, gamma, W, xn,
-                       mean, rstd, dx, (__bf16*)dx_act, dW, dbias, dgamma, dbeta, D, n_class);
-  else if (act_dtype == PM_F32)
-    hipLaunchKernelGGL(cls_head_bwd_kernel<float>, dim3(B), dim3(256), 0, pm_stream(stream), dlogits, x, N, gamma, W, xn,
-                       mean, rstd, dx, (float*)dx_act, dW, dbias, dgamma, dbeta, D, n_class);
-  else
-    return PM_EINVAL;
-  if (dW || dbias || dgamma || dbeta)
-    hipLaunchKernelGGL(cls_head_pgrad_kernel, dim3((D + 255) / 256), dim3(256), 0, pm_stream(stream), dlogits, x, (long)N * D, W,
-                       xn, mean, rstd, dW, dbias, dgamma, dbeta, B, D, n_class);
-  return pm_check_launch();
-}
-
 extern "C" int pm_adamw(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long n, float lr,
                         float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                         void* stream) {
@@ -638,4 +452,25 @@ extern "C" const char* pm_strerror(int status) {
   }
 }
 
-extern "C" int pm_abi_version(void) { return 2; }  // 2: pm_mae_unshuffle_bwd workspace, pm_gemm_colsum, pm_preprocess_u8, pm_tune
+// 3: pm_gemm_ex / pm_gemm_opts replace pm_tune, workspace queries, pm_vit_head_*, pm_supervised_loss_fwd, pm_scale
+extern "C" int pm_abi_version(void) { return 3; }
+
+extern "C" size_t pm_workspace_bytes(int kind, int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  switch (kind) {
+    case PM_WS_LAYERNORM_BWD: {  // one partial row triple per block, grid = min(ceil(M/4), 1024)
+      long g = (M + 3) / 4;
+      if (g > 1024) g = 1024;
+      if (g < 64) g = 64;
+      return (size_t)g * 3 * N * sizeof(float);
+    }
+    case PM_WS_COLSUM: return (size_t)cap_grid(M, 64, 128) * N * sizeof(float);
+    case PM_WS_GEMM_COLSUM: {  // per (row tile of 192, wave row) partial rows of the fused epilogue, or the plain column sum
+      const size_t fused = (size_t)((M + 191) / 192) * 2 * N * sizeof(float);
+      const size_t plain = (size_t)cap_grid(M, 64, 128) * N * sizeof(float);
+      return fused > plain ? fused : plain;
+    }
+    case PM_WS_UNSHUFFLE_BWD: return (size_t)128 * N * sizeof(float);
+    default: return 0;
+  }
+}

@@ -19,6 +19,7 @@ from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import contextlib
+import ctypes
 import os
 
 import torch
@@ -59,28 +60,41 @@ class Kernels:
                                              _ptr(mean), _ptr(rstd), M, D, self.eps, _stream()), "pm_layernorm_fwd")
 
     def layernorm_bwd(self, dy, x, gamma, mean, rstd, dres, dx, dx_act, dgamma, dbeta, dcolsum, M, D):
-        ws = self._ln_workspace(x.device)
+        ws = self._scratch("_ws_ln", self._need(("ln", M, D), lambda: self.lib.pm_workspace_bytes(_lib.WS_LAYERNORM_BWD, M, D)),
+                           x.device)
         _lib.check(self.lib.pm_layernorm_bwd(_ptr(dy), _lib.dtype_code(dy.dtype), _ptr(x), D, _ptr(gamma), _ptr(mean),
                                              _ptr(rstd), _ptr(dres), D, _ptr(dx), D, _ptr(dx_act), self.act,
                                              _ptr(dgamma), _ptr(dbeta), _ptr(dcolsum), M, D, _ptr(ws), ws.numel(), _stream()),
                    "pm_layernorm_bwd")
 
     SPLIT_FORWARD = int(os.environ.get("PM_SPLIT_FWD", "2"))  # forward: this many sub-batches as concurrent chains (1 = off)
+    # workgroups a split-K weight gradient spreads over (pm_gemm_opts.max_blocks): the weight gradients run beside the
+    # dgrad chain on a side stream, so each takes ~half of the CUs and leaves the rest to LayerNorm / attention backward /
+    # dgrad GEMMs (measured: 128 best of 96..256)
     WGRAD_BLOCKS = int(os.environ.get("PM_WGRAD_BLOCKS", "128"))
     # fc1.bias gradient inside the dGELU dgrad epilogue (pm_gemm_colsum) instead of a column-sum kernel on the side
     # stream.  Off: the HBM-bound column sum overlaps the MFMA-bound GEMMs for free, while the fused reduction
     # lengthens the dgrad chain (measured -2.5 % step rate when fused).
     FUSE_COLSUM = os.environ.get("PM_FUSE_COLSUM", "0") == "1"
-    SPLITK_WS_BYTES = 96 << 20  # scratch for split-K wgrad slabs (16 x the largest weight of ViT-B would be 151 MB;
-    #                             pm_gemm_ws picks the largest split that fits)
+    gemm_variant = 0  # pm_gemm_opts.variant: 0 = the dispatcher's heuristics (tuning scripts set it per Kernels object)
 
-    def _ln_workspace(self, device):
-        """Per-block partial column sums of the LayerNorm backward (separate from the split-K slabs: the wgrad GEMMs
-        run concurrently on the side stream)."""
-        ws = getattr(self, "_ws_ln", None)
-        if ws is None or ws.device != device:
-            ws = torch.empty(1024 * 3 * 1024 * 4, dtype=torch.uint8, device=device)
-            self._ws_ln = ws
+    # -- scratch buffers: sized by the library's own queries (pm_gemm_workspace_bytes / pm_workspace_bytes), cached per
+    #    shape; a buffer only ever grows, and growing it (first step of a new shape) drains the device first because the
+    #    side stream may still be using the old one
+    def _need(self, key, query) -> int:
+        cache = self.__dict__.setdefault("_need_cache", {})
+        n = cache.get(key)
+        if n is None:
+            n = cache[key] = int(query())
+        return n
+
+    def _scratch(self, name: str, nbytes: int, device) -> torch.Tensor:
+        ws = getattr(self, name, None)
+        if ws is None or ws.device != device or ws.numel() < nbytes:
+            if ws is not None and ws.device == device:
+                torch.cuda.synchronize(device)
+            ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+            setattr(self, name, ws)
         return ws
 
     def aux_stream(self, device, j: int = 0):
@@ -97,32 +111,35 @@ class Kernels:
         if st is None or st.device != device:
             st = torch.cuda.Stream(device=device)
             self._side = st
-            # the weight gradients run beside the dgrad chain: spread each over ~half of the CUs so that the chain
-            # (LayerNorm / attention backward, dgrad GEMMs) is not starved (measured: 128 best of 96..256)
-            _lib.check(min(self.lib.pm_tune(_lib.TUNE_WGRAD_BLOCKS, self.WGRAD_BLOCKS), 0), "pm_tune")
         return st
 
-    def _workspace(self, device):
-        ws = getattr(self, "_ws", None)
-        if ws is None or ws.device != device:
-            ws = torch.empty(self.SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
-            self._ws = ws
-        return ws
+    def _opts(self, wgrad: bool):
+        o = self.__dict__.get("_opts_cache")
+        if o is None or o[0] != (self.WGRAD_BLOCKS, self.gemm_variant):
+            key = (self.WGRAD_BLOCKS, self.gemm_variant)
+            o = self._opts_cache = (key, _lib.GemmOpts(self.WGRAD_BLOCKS, self.gemm_variant), _lib.GemmOpts(0, self.gemm_variant))
+        return o[1] if wgrad else o[2]
 
     def gemm(self, A, lda, a_kmajor, B, ldb, b_kmajor, bias, C, ldc, epilogue, M, N, K, aux=None, resid=None, colsum=None):
         in_dtype = _lib.dtype_code(A.dtype)
         if _lib.dtype_code(B.dtype) != in_dtype:
             raise _lib.PolypMaeError("pm_gemm: operand dtypes differ")
         if colsum is not None:  # colsum[n] += sum_m C[m][n], fused into the epilogue where the kernel supports it
-            ws = self._colsum_workspace(A.device)
+            ws = self._colsum_workspace(A.device, M, N, True)
             _lib.check(self.lib.pm_gemm_colsum(_ptr(A), lda, int(a_kmajor), _ptr(B), ldb, int(b_kmajor), in_dtype, _ptr(bias),
                                                _ptr(C), ldc, _lib.dtype_code(C.dtype), epilogue, _ptr(aux), _ptr(resid),
                                                _ptr(colsum), M, N, K, _ptr(ws), ws.numel(), _stream()), "pm_gemm_colsum")
             return
-        ws = self._workspace(A.device) if (a_kmajor and b_kmajor) else None
-        _lib.check(self.lib.pm_gemm_ws(_ptr(A), lda, int(a_kmajor), _ptr(B), ldb, int(b_kmajor), in_dtype, _ptr(bias),
+        wgrad = bool(a_kmajor and b_kmajor)
+        opts = self._opts(wgrad)
+        ws = None
+        if wgrad:
+            need = self._need(("gemm", in_dtype, M, N, K, opts.max_blocks, opts.variant),
+                              lambda: self.lib.pm_gemm_workspace_bytes(1, 1, in_dtype, M, N, K, ctypes.byref(opts)))
+            ws = self._scratch("_ws", need, A.device)
+        _lib.check(self.lib.pm_gemm_ex(_ptr(A), lda, int(a_kmajor), _ptr(B), ldb, int(b_kmajor), in_dtype, _ptr(bias),
                                        _ptr(C), ldc, _lib.dtype_code(C.dtype), epilogue, _ptr(aux), _ptr(resid), M, N, K,
-                                       _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "pm_gemm")
+                                       _ptr(ws), ws.numel() if ws is not None else 0, ctypes.byref(opts), _stream()), "pm_gemm")
 
     def linear_fwd(self, x, W, bias, out, M, N, K, epilogue=EPI_STORE, aux=None, resid=None):
         """out[M,N] = x[M,K] @ W[N,K]^T + bias  (nn.Linear forward)."""
@@ -136,18 +153,15 @@ class Kernels:
         """dW[N_out,K_in] (+)= dy[M,N_out]^T @ x[M,K_in]  (both operands k-major, f32 output)."""
         self.gemm(dy, N_out, 1, x, K_in, 1, None, dW, K_in, EPI_ACCUM if accumulate else EPI_STORE, N_out, K_in, M)
 
-    def _colsum_workspace(self, device):
+    def _colsum_workspace(self, device, M: int, N: int, fused: bool = False):
         # partial rows: one scratch per stream (main / wgrad side stream) so concurrent column sums never share it
         on_side = getattr(self, "_side", None) is not None and torch.cuda.current_stream() == self._side
-        key = "_ws_cs_side" if on_side else "_ws_cs_main"
-        ws = getattr(self, key, None)
-        if ws is None or ws.device != device:
-            ws = torch.empty(8 << 20, dtype=torch.uint8, device=device)
-            setattr(self, key, ws)
-        return ws
+        kind = _lib.WS_GEMM_COLSUM if fused else _lib.WS_COLSUM
+        need = self._need(("cs", kind, M, N), lambda: self.lib.pm_workspace_bytes(kind, M, N))
+        return self._scratch("_ws_cs_side" if on_side else "_ws_cs_main", need, device)
 
     def colsum(self, x, out, M, N):
-        ws = self._colsum_workspace(x.device)
+        ws = self._colsum_workspace(x.device, M, N)
         _lib.check(self.lib.pm_colsum_ws(_ptr(x), N, _lib.dtype_code(x.dtype), _ptr(out), M, N, _ptr(ws), ws.numel(),
                                          _stream()), "pm_colsum")
 

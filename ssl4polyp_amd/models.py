@@ -239,47 +239,60 @@ class _EncoderFrontMixin:
 
 
 class _VitClsFn(torch.autograd.Function):
-    """imgs -> logits for ViT_from_MAE / VisionTransformer_from_Any (models.py:129-140, 211-222), one node."""
+    """imgs -> logits (head) or features (head=False) for ViT_from_MAE / VisionTransformer_from_Any
+    (models.py:129-140, 211-222), one node.  pool: 0 = out_token "cls", 1 = "spatial"."""
 
     @staticmethod
-    def forward(ctx, rt: _Runtime, imgs: torch.Tensor, names, *params):
+    def forward(ctx, rt: _Runtime, imgs: torch.Tensor, pool: int, head: bool, names, *params):
         k, f, mod, g = rt.k, rt.flat, rt.module, rt.enc_geom
         B = imgs.shape[0]
         L = mod.patch_embed.num_patches
         N = L + 1
         D = g.dim
-        training = any(ctx.needs_input_grad)  # (grad mode is already off inside Function.forward)
+        needs = ctx.needs_input_grad[5:]
+        # (grad mode is already off inside Function.forward.)  Linear probe (finetune.py mode "none": only lin_head
+        # trains): nothing below the head needs saved activations -> the forward-only workspace (2 blocks instead of 12).
+        below = any(nd for n, nd in zip(names, needs) if not n.startswith("lin_head"))
+        training = any(needs)
         imgs = imgs.contiguous().float()
         cols, x0 = _EncoderFrontMixin.front_fwd(rt, imgs, None, L)
-        ws = rt.get_ws(g, B, N, training)
+        ws = rt.get_ws(g, B, N, below)
         W, _ = rt.stack_weights("blocks.", g.depth)
         x = BlockStack(k, g).forward(ws, x0, W, before_block=_update_gate(rt, "blocks."))
         rt.wait_updates()  # norm / lin_head and anything else still pending
-        n_class = mod.lin_head.weight.shape[0]
         dev = imgs.device
-        xn = torch.empty(B, D, dtype=torch.float32, device=dev)
-        mean = torch.empty(B, dtype=torch.float32, device=dev)
-        rstd = torch.empty(B, dtype=torch.float32, device=dev)
-        logits = torch.empty(B, n_class, dtype=torch.float32, device=dev)
-        _lib.check(k.lib.pm_cls_head_fwd(_ptr(x), N, _ptr(f.param_view("norm.weight")), _ptr(f.param_view("norm.bias")),
-                                         _ptr(f.param_view("lin_head.weight")), _ptr(f.param_view("lin_head.bias")),
-                                         _ptr(xn), _ptr(mean), _ptr(rstd), _ptr(logits), B, D, n_class, rt.eps, _stream()),
-                   "pm_cls_head_fwd")
+        f32 = torch.float32
+        n_class = mod.lin_head.weight.shape[0] if head else 0
+        feat = torch.empty(B, D, dtype=f32, device=dev)
+        xhm = torch.empty(B, D, dtype=f32, device=dev) if pool else None
+        mean = torch.empty(B * (N if pool else 1), dtype=f32, device=dev)
+        rstd = torch.empty_like(mean)
+        logits = torch.empty(B, n_class, dtype=f32, device=dev) if head else None
+        _lib.check(k.lib.pm_vit_head_fwd(_ptr(x), N, pool, _ptr(f.param_view("norm.weight")), _ptr(f.param_view("norm.bias")),
+                                         _ptr(f.param_view("lin_head.weight")) if head else None,
+                                         _ptr(f.param_view("lin_head.bias")) if head else None, _ptr(feat), _ptr(xhm),
+                                         _ptr(mean), _ptr(rstd), _ptr(logits), B, D, n_class, rt.eps, _stream()),
+                   "pm_vit_head_fwd")
         if training:
             ctx.rt, ctx.names, ctx.ws = rt, names, ws
-            ctx.saved = (cols, x0, x, xn, mean, rstd)
-            ctx.dims = (B, L, N, D, n_class)
+            if not below:  # the head's backward reads only the last block's output rows: keep those, release the rest
+                x = x.clone() if pool else x.view(B, N, D)[:, 0].clone()
+                rt.put_ws(g, ws)
+                ctx.ws = None
+                cols = x0 = None
+            ctx.saved = (cols, x0, x, feat, xhm, mean, rstd)
+            ctx.dims = (B, L, N, D, n_class, pool, head, below)
         else:
             rt.put_ws(g, ws)
-        return logits
+        return logits if head else feat
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dout):
         rt, names, ws = ctx.rt, ctx.names, ctx.ws
         k, f, mod, g = rt.k, rt.flat, rt.module, rt.enc_geom
-        cols, x0, x, xn, mean, rstd = ctx.saved
-        B, L, N, D, n_class = ctx.dims
-        needs = list(ctx.needs_input_grad[3:])
+        cols, x0, x, feat, xhm, mean, rstd = ctx.saved
+        B, L, N, D, n_class, pool, head, below = ctx.dims
+        needs = list(ctx.needs_input_grad[5:])
         need_map = dict(zip(names, needs))
         need = lambda n: need_map.get(n, False)
         accumulate = _plan_grads(rt, names, needs)
@@ -290,16 +303,18 @@ class _VitClsFn(torch.autograd.Function):
         front = need("cls_token") or need("patch_embed.proj.weight") or need("patch_embed.proj.bias") or \
             (learn_pos and need("pos_embed"))
         below_head = front or any(trainable)
-        dlogits = dlogits.contiguous().float()
+        dout = dout.contiguous().float()
         dx = ws.dx[0] if below_head else None
         dx_act = ws.dx_act[0] if below_head else None
-        _lib.check(k.lib.pm_cls_head_bwd(
-            _ptr(dlogits), _ptr(x), N, _ptr(f.param_view("norm.weight")), _ptr(f.param_view("lin_head.weight")), _ptr(xn),
+        x_rows = N if (below or pool) else 1   # linear probe, cls token: only the saved cls rows [B, 1, D]
+        _lib.check(k.lib.pm_vit_head_bwd(
+            _ptr(dout) if head else None, None if head else _ptr(dout), _ptr(x), x_rows, pool,
+            _ptr(f.param_view("norm.weight")), _ptr(f.param_view("lin_head.weight")) if head else None, _ptr(feat), _ptr(xhm),
             _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dx_act), k.act,
             _ptr(f.grad_view("lin_head.weight")) if need("lin_head.weight") else None,
             _ptr(f.grad_view("lin_head.bias")) if need("lin_head.bias") else None,
             _ptr(f.grad_view("norm.weight")) if need("norm.weight") else None,
-            _ptr(f.grad_view("norm.bias")) if need("norm.bias") else None, B, D, n_class, _stream()), "pm_cls_head_bwd")
+            _ptr(f.grad_view("norm.bias")) if need("norm.bias") else None, B, D, n_class, _stream()), "pm_vit_head_bwd")
         sync = rt.grad_sync
         if below_head:
             W, G = rt.stack_weights("blocks.", g.depth)
@@ -311,10 +326,58 @@ class _VitClsFn(torch.autograd.Function):
                 _EncoderFrontMixin.front_bwd(rt, dx0, cols, None, B, L, accumulate, need, learn_pos)
         if sync is not None:
             sync.backward_done()
-        rt.put_ws(g, ws)
+        if ws is not None:
+            rt.put_ws(g, ws)
         ctx.saved = None
         grads = [None if (accumulate or not nd) else f.grad_view(n) for n, nd in zip(names, needs)]
-        return (None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
+
+
+class _SupervisedLossFn(torch.autograd.Function):
+    """logits [B, n_class], targets int64 [B] -> scalar loss (tc.py:3347-3374, 6086-6104), value and d loss / d logits
+    from one launch (pm_supervised_loss_fwd); backward scales the saved gradient by the upstream scalar (pm_scale)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, pos_weight, class_weights):
+        if not logits.is_cuda:
+            raise _lib.PolypMaeError("supervised_loss runs on the MI355X HIP path only (got a CPU tensor)")
+        lib = _lib.load()
+        logits = logits.contiguous().float()
+        targets = targets.contiguous().to(torch.int64)
+        B, C = logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        _lib.check(lib.pm_supervised_loss_fwd(_ptr(logits), _ptr(targets), _ptr(pos_weight), _ptr(class_weights), _ptr(loss),
+                                              _ptr(dlogits), B, C, _stream()), "pm_supervised_loss_fwd")
+        ctx.dlogits = dlogits
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        d = ctx.dlogits
+        out = torch.empty_like(d)
+        dloss = dloss.reshape(1).contiguous().float()
+        _lib.check(lib.pm_scale(_ptr(d), _ptr(dloss), _ptr(out), d.numel(), _stream()), "pm_scale")
+        return out, None, None, None
+
+
+def supervised_loss(logits: torch.Tensor, targets: torch.Tensor, pos_weight=None, class_weights=None) -> torch.Tensor:
+    """The fine-tune loss of train_classification.py:3347-3374 / 6086-6104 as one HIP op: two classes ->
+    BCEWithLogitsLoss(pos_weight) on logits[:,1]-logits[:,0]; more -> CrossEntropyLoss(weight=class_weights).
+    pos_weight: python float or a DEVICE scalar tensor; class_weights: f32 [n_class] on the device."""
+    dev = logits.device
+    if pos_weight is not None and not torch.is_tensor(pos_weight):
+        pos_weight = torch.tensor(float(pos_weight), dtype=torch.float32, device=dev)
+    if pos_weight is not None:
+        pos_weight = pos_weight.to(device=dev, dtype=torch.float32).reshape(1)
+    if class_weights is not None:
+        class_weights = class_weights.to(device=dev, dtype=torch.float32).contiguous()
+        if class_weights.numel() != logits.shape[1]:
+            raise ValueError("class_weights must have one entry per class")
+    if logits.ndim != 2 or logits.shape[1] < 2:
+        raise ValueError("supervised_loss expects logits [B, n_class >= 2]")
+    return _SupervisedLossFn.apply(logits, targets, pos_weight, class_weights)
 
 
 class _MaeFn(torch.autograd.Function):
@@ -435,7 +498,8 @@ class _MaeFn(torch.autograd.Function):
                                              True, acc_fn, cb_d)
         # -- un-shuffle + decoder_embed
         demb_act = torch.empty(Me, Dd, dtype=k.act_dtype, device=dev)
-        cs_ws = k._colsum_workspace(dev)  # partial rows of the mask-token sum (fixed-order second stage)
+        # partial rows of the mask-token sum (fixed-order second stage)
+        cs_ws = k._scratch("_ws_cs_main", k._need(("unshuf", Dd), lambda: k.lib.pm_workspace_bytes(_lib.WS_UNSHUFFLE_BWD, 1, Dd)), dev)
         _lib.check(k.lib.pm_mae_unshuffle_bwd(_ptr(dxd0), _ptr(ids_shuffle), _ptr(demb_act), k.act,
                                               _ptr(f.grad_view("mask_token")) if need("mask_token") else None, B, L, keep,
                                               Dd, _ptr(cs_ws), cs_ws.numel(), _stream()), "pm_mae_unshuffle_bwd")
@@ -598,16 +662,13 @@ class _ClassifierBase(nn.Module):
         if self.dense:
             raise NotImplementedError("dense (DPT decoder) mode is dead code on the reference's path (every caller "
                                       "passes dense=None, tc.py:5646-5654) and is not built")
-        if self.out_token != "cls":
-            raise NotImplementedError("out_token='spatial' is not on the shipped path (default 'cls', "
-                                      "utils/__init__.py:29,52)")
-        head = self.head if isinstance(self.head, bool) else self.head_bool
-        if not head:
-            raise NotImplementedError("head=False (feature output) is not on the shipped path")
+        if self.out_token not in ("cls", "spatial"):
+            raise ValueError(f"out_token must be 'cls' or 'spatial' (got {self.out_token!r})")  # models.py:134-137,216-219
+        head = bool(self.head if isinstance(self.head, bool) else self.head_bool)
         rt = self._rt
         rt.ensure(imgs.device)
         assert imgs.shape[2] == self.patch_embed.img_size[0] and imgs.shape[3] == self.patch_embed.img_size[1]
-        return _VitClsFn.apply(rt, imgs, rt.flat.names, *rt.flat.params)
+        return _VitClsFn.apply(rt, imgs, 1 if self.out_token == "spatial" else 0, head, rt.flat.names, *rt.flat.params)
 
 
 class ViT_from_MAE(_ClassifierBase):

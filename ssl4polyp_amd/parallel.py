@@ -14,12 +14,18 @@ into one flat f32 range in forward order and finishes it back-to-front during ba
   * xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large but no larger than one transformer block
     (default 24 MiB < the 28 MiB of a ViT-B block's matrices, so a bucket closes at every block boundary: 12-13
     collectives per step, >= 3.5 MiB per link per ring step) -- the last bucket is the only one the backward cannot
-    hide, so its size is the exposed tail.
+    hide, so its size is the exposed tail;
+  * only TRAINABLE ranges travel: the plan is the set of flat segments whose parameters have ``requires_grad=True``
+    (merged across gaps below ``merge_gap`` elements -- a frozen positional table between two trainable vectors costs
+    less on the wire than a second collective), rebuilt whenever the set changes.  The staged fine-tune schedule of the
+    reference (finetune.py:49-126 applied by train_classification.py:924-953: none -> head+1 -> head+2 -> full)
+    flips ``requires_grad`` between epochs; torch DDP fixes its reducer at construction, this one follows the flags:
+    linear probe ("none") all-reduces lin_head only (6 KB instead of 343 MB).
 Gradients are summed; the mean is folded into the fused AdamW (``grad_scale = 1/world``).
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -27,27 +33,68 @@ import torch.nn as nn
 
 
 class GradSync:
-    def __init__(self, rt, process_group=None, bucket_mb: float = 24.0):
+    def __init__(self, rt, process_group=None, bucket_mb: float = 24.0, merge_gap: int = 1 << 18, force: bool = False):
         self.rt = rt
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
-        self.enabled = True  # False inside no_sync() (gradient accumulation micro-steps)
+        self.merge_gap = int(merge_gap)
+        self.force = bool(force)  # run the collectives at world size 1 too (tests: exercises the RCCL stream semantics)
+        self.enabled = True       # False inside no_sync() (gradient accumulation micro-steps)
         self.comm_stream: Optional[torch.cuda.Stream] = None
         self._works: List = []
-        self._hi = None       # everything in mat[_hi:] has been handed to RCCL
+        self._hi = None           # everything in mat[_hi:] has been handed to RCCL
         self._armed = False
+        self._plan_key = None
+        self._ranges: Dict[str, List[Tuple[int, int]]] = {"mat": [], "vec": []}
+        self.launched: List[Tuple[str, int, int]] = []  # (region, lo, hi) of the last backward's collectives (tests / logs)
+        self.plan_builds = 0
 
     # ------------------------------------------------------------------------------------------
+    @property
+    def active(self) -> bool:
+        return self.enabled and (self.world > 1 or self.force)
+
+    def _plan(self):
+        """Trainable flat segments per region, merged across small gaps; rebuilt when requires_grad flags change."""
+        f = self.rt.flat
+        key = (id(f.P.get("mat")), tuple(p.requires_grad for p in f.params))
+        if key == self._plan_key:
+            return
+        A = f.ALIGN
+        segs: Dict[str, List[Tuple[int, int]]] = {"mat": [], "vec": []}
+        for i, p in enumerate(f.params):
+            if p.requires_grad:
+                segs[f.region[i]].append((f.offset[i], f.offset[i] + (f.numel[i] + A - 1) // A * A))
+        for r, lst in segs.items():
+            lst.sort()
+            merged: List[Tuple[int, int]] = []
+            for lo, hi in lst:
+                if merged and lo - merged[-1][1] <= self.merge_gap:
+                    merged[-1] = (merged[-1][0], max(hi, merged[-1][1]))
+                else:
+                    merged.append((lo, hi))
+            self._ranges[r] = merged
+        self._plan_key = key
+        self.plan_builds += 1
+
+    def trainable_bytes(self) -> int:
+        self._plan()
+        return 4 * sum(hi - lo for r in self._ranges.values() for lo, hi in r)
+
     def _begin(self):
         f = self.rt.flat
         if self.comm_stream is None and f.device.type == "cuda":
             self.comm_stream = torch.cuda.Stream(device=f.device)
+        self._plan()
         self._hi = f.G["mat"].numel()
         self._works = []
+        self.launched = []
         self._armed = True
 
-    def _launch(self, tensor):
+    def _launch(self, region: str, lo: int, hi: int):
+        tensor = self.rt.flat.G[region][lo:hi]
+        self.launched.append((region, lo, hi))
         if not tensor.is_cuda:  # gloo rehearsal of the bucket schedule on CPU (tests)
             self._works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             return
@@ -57,51 +104,71 @@ class GradSync:
         with torch.cuda.stream(self.comm_stream):
             self._works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
+    def _pending(self, lo: int, hi: int) -> List[Tuple[int, int]]:
+        """Trainable pieces of mat[lo:hi), back to front."""
+        out = []
+        for a, b in reversed(self._ranges["mat"]):
+            a2, b2 = max(a, lo), min(b, hi)
+            if a2 < b2:
+                out.append((a2, b2))
+        return out
+
     def _ready_down_to(self, lo: int, force: bool):
-        """mat[lo:] is final.  Hand [lo, _hi) to RCCL if it is a full bucket (or `force`)."""
+        """mat[lo:] is final.  Hand the trainable part of [lo, _hi) to RCCL if it fills a bucket (or `force`)."""
         if not self._armed:
             self._begin()
-        if lo < self._hi and (force or self._hi - lo >= self.bucket_elems):
-            self._launch(self.rt.flat.G["mat"][lo:self._hi])
+        if lo >= self._hi:
+            return
+        pieces = self._pending(lo, self._hi)
+        if not pieces:
+            self._hi = lo
+            return
+        if force or sum(b - a for a, b in pieces) >= self.bucket_elems:
+            for a, b in pieces:
+                self._launch("mat", a, b)
             self._hi = lo
 
     # -- called by the engine ----------------------------------------------------------------------
     def block_done(self, prefix: str, i: int):
-        if not self.enabled or self.world == 1:
+        if not self.active:
             return
         f = self.rt.flat
         self._ready_down_to(f.offset[f.index[f"{prefix}{i}.attn.qkv.weight"]], force=False)
 
     def backward_done(self, in_backward: bool = True):
-        if not self.enabled or self.world == 1:
+        if not self.active:
             return
         self._ready_down_to(0, force=True)
-        self._launch(self.rt.flat.G["vec"])
+        for a, b in self._ranges["vec"]:
+            self._launch("vec", a, b)
         self._armed = False
         if in_backward:
             # make the compute stream wait for RCCL at the end of this backward pass (before any optimizer)
             torch.autograd.Variable._execution_engine.queue_callback(self.wait)
 
     def wait(self):
+        """Order the CURRENT stream after every collective of the last backward (RCCL: a stream-side event wait, no host
+        block; gloo: blocks the host).  Idempotent: the autograd end-of-backward callback and the optimizer both call it,
+        whichever stream / thread they run on; the list is dropped when the next backward arms the synchroniser."""
         for w in self._works:
-            w.wait()  # stream-side wait on the current (compute) stream
-        self._works = []
+            w.wait()
 
 
 class DataParallel(nn.Module):
     """Thin wrapper: broadcast parameters from rank 0, attach the gradient synchroniser to the module's runtime."""
 
-    def __init__(self, module: nn.Module, device: torch.device, process_group=None, bucket_mb: float = 24.0):
+    def __init__(self, module: nn.Module, device: torch.device, process_group=None, bucket_mb: float = 24.0,
+                 force_sync: bool = False):
         super().__init__()
         self.module = module
         module.to(device)
         rt = module._rt
         rt.ensure(device)
-        if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        if dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force_sync):
             for r in ("vec", "mat"):
                 dist.broadcast(rt.flat.P[r], src=0, group=process_group)
             rt.flat._shadow_versions = None  # force a shadow refresh from the broadcast weights
-            self.sync = GradSync(rt, process_group, bucket_mb)
+            self.sync = GradSync(rt, process_group, bucket_mb, force=force_sync)
             rt.grad_sync = self.sync
         else:
             self.sync = None

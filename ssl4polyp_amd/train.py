@@ -22,7 +22,6 @@ from typing import Callable, Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
-import torch.nn.functional as F
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -57,10 +56,10 @@ def cls_cosine_lambda(epoch: int, warmup_epochs: int, total_epochs: int) -> floa
 # ---------------------------------------------------------------------------------------------------
 def supervised_loss(logits: torch.Tensor, targets: torch.Tensor, pos_weight: Optional[torch.Tensor] = None,
                     class_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
-    if logits.ndim == 2 and logits.size(1) == 2:  # binary_bce mode
-        z = logits[:, 1] - logits[:, 0]
-        return F.binary_cross_entropy_with_logits(z, targets.to(z.dtype), pos_weight=pos_weight)
-    return F.cross_entropy(logits, targets, weight=class_weights)
+    """One HIP launch for the loss and its gradient (pm_supervised_loss_fwd) instead of ~10 small ATen kernels; runs on
+    the GPU only, like the rest of the product path."""
+    from .models import supervised_loss as _hip_loss
+    return _hip_loss(logits, targets, pos_weight, class_weights)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -211,14 +210,53 @@ def class_probabilities(logits: torch.Tensor) -> torch.Tensor:
     return torch.softmax(logits, dim=-1)
 
 
+class _RankBatches:
+    """Batch sampler view: batches rank, rank + world, ... of an existing batch sampler (loader order preserved)."""
+
+    def __init__(self, batch_sampler, rank: int, world: int, max_batches: Optional[int] = None):
+        self.bs, self.rank, self.world, self.max_batches = batch_sampler, rank, world, max_batches
+
+    def __iter__(self):
+        for i, b in enumerate(self.bs):
+            if self.max_batches is not None and i >= self.max_batches:
+                return
+            if i % self.world == self.rank:
+                yield b
+
+    def __len__(self):
+        n = len(self.bs) if self.max_batches is None else min(len(self.bs), self.max_batches)
+        return (n - self.rank + self.world - 1) // self.world if n > self.rank else 0
+
+
+def shard_eval_loader(loader, rank: int, world: int, max_batches: Optional[int] = None):
+    """This rank's share of an evaluation loader as (global batch index, batch) pairs.  A torch DataLoader is rebuilt
+    around a rank-local batch sampler, so its workers only open / decode / transform this rank's frames (PackDataset does
+    PIL open + transform per item, data/packs.py:70-80); any other iterable is walked with the foreign batches skipped."""
+    from torch.utils.data import DataLoader
+    if isinstance(loader, DataLoader) and loader.batch_sampler is not None:
+        kw = dict(num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
+                  worker_init_fn=loader.worker_init_fn, timeout=loader.timeout, generator=loader.generator)
+        if loader.num_workers > 0:
+            kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=False)
+        mine = DataLoader(loader.dataset, batch_sampler=_RankBatches(loader.batch_sampler, rank, world, max_batches), **kw)
+        for j, batch in enumerate(mine):
+            yield rank + j * world, batch
+        return
+    for it, batch in enumerate(loader):
+        if max_batches is not None and it >= max_batches:
+            break
+        if it % world == rank:
+            yield it, batch
+
+
 @torch.no_grad()
 def evaluate_cls(model, loader: Iterable, device, max_batches: Optional[int] = None, shard: Optional[bool] = None,
                  return_probs: bool = False):
     """tc.py:4652-4812 forward part: forward-only kernels in eval mode; logits (and optionally on-device probabilities)
     and targets gathered on the host (metrics stay in the reference's code).
-    shard (default: whenever torch.distributed is initialised with world > 1): every rank walks the SAME loader and
-    evaluates batches i with i % world == rank; the pieces are all-gathered and returned in loader order on every rank
-    -- the reference validates on rank 0 only while the other GPUs idle (tc.py:6660-6728)."""
+    shard (default: whenever torch.distributed is initialised with world > 1): rank r evaluates batches r, r + world, ...
+    through a rank-local batch sampler (it never decodes another rank's frames); the pieces are all-gathered and returned
+    in loader order on every rank -- the reference validates on rank 0 only while the other GPUs idle (tc.py:6660-6728)."""
     model.eval()
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
@@ -227,11 +265,7 @@ def evaluate_cls(model, loader: Iterable, device, max_batches: Optional[int] = N
     if not shard:
         world, rank = 1, 0
     mine = []
-    for it, batch in enumerate(loader):
-        if max_batches is not None and it >= max_batches:
-            break
-        if it % world != rank:
-            continue
+    for it, batch in shard_eval_loader(loader, rank, world, max_batches):
         lg = model(batch[0].to(device, non_blocking=True)).float()
         pr = class_probabilities(lg) if return_probs else None
         mine.append((it, lg.cpu(), batch[1].cpu(), pr.cpu() if pr is not None else None))

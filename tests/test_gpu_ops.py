@@ -458,3 +458,94 @@ def test_cls_head_and_adamw():
                                   _stream()), "adamw")
     assert rel(p1, pt.detach()) < 2e-6
     assert torch.equal(shadow, p1.bfloat16())
+
+
+@pytest.mark.parametrize("pool", [0, 1])
+@pytest.mark.parametrize("head", [True, False])
+@pytest.mark.parametrize("D,N,nc", [(768, 197, 2), (64, 17, 5), (512, 50, 11)])
+def test_vit_head_pool_and_head_modes(pool, head, D, N, nc):
+    """pm_vit_head_fwd / _bwd: final LayerNorm + token selection (cls row | mean of the patch rows) + optional lin_head
+    (models.py:134-139, 216-221), every mode against autograd of the same torch expression."""
+    from ssl4polyp_amd import _lib
+    from ssl4polyp_amd.engine import _ptr, _stream
+    k = _k("bf16")
+    B = 5
+    x = rnd(B, N, D, seed=190, scale=1.5) + 0.3
+    gamma, beta = 1 + 0.1 * rnd(D, seed=191), 0.1 * rnd(D, seed=192)
+    W, bias = rnd(nc, D, seed=193, scale=0.05), rnd(nc, seed=194)
+    feat = torch.empty(B, D, device=DEV)
+    xhm = torch.empty(B, D, device=DEV) if pool else None
+    mean = torch.empty(B * (N if pool else 1), device=DEV)
+    rstd = torch.empty_like(mean)
+    logits = torch.empty(B, nc, device=DEV) if head else None
+    _lib.check(k.lib.pm_vit_head_fwd(_ptr(x), N, pool, _ptr(gamma), _ptr(beta), _ptr(W) if head else None,
+                                     _ptr(bias) if head else None, _ptr(feat), _ptr(xhm), _ptr(mean), _ptr(rstd), _ptr(logits),
+                                     B, D, nc if head else 0, 1e-6, _stream()), "vit_head_fwd")
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    Wr, bbr = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (D,), gr, br, 1e-6)
+    fr = y[:, 1:].mean(1) if pool else y[:, 0]
+    assert rel(feat, fr) < 1e-5
+    ref = F.linear(fr, Wr, bbr) if head else fr
+    if head:
+        assert rel(logits, ref) < 1e-5
+    dout = rnd(*ref.shape, seed=195)
+    ref.backward(dout)
+    dx = torch.full((B, N, D), float("nan"), device=DEV)
+    dxa = torch.empty(B, N, D, dtype=torch.bfloat16, device=DEV)
+    dW, dbias = torch.zeros(nc, D, device=DEV), torch.zeros(nc, device=DEV)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    _lib.check(k.lib.pm_vit_head_bwd(_ptr(dout) if head else None, None if head else _ptr(dout), _ptr(x), N, pool, _ptr(gamma),
+                                     _ptr(W) if head else None, _ptr(feat), _ptr(xhm), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dxa), 1,
+                                     _ptr(dW) if head else None, _ptr(dbias) if head else None, _ptr(dg), _ptr(db), B, D,
+                                     nc if head else 0, _stream()), "vit_head_bwd")
+    assert rel(dx, xr.grad) < 2e-5 and rel(dg, gr.grad) < 2e-5 and rel(db, br.grad) < 2e-5
+    assert rel(dxa.float(), xr.grad) < 8e-3
+    if head:
+        assert rel(dW, Wr.grad) < 1e-5 and rel(dbias, bbr.grad) < 1e-5
+    # frozen backbone: parameter gradients only, dx == NULL
+    dW2, dg2 = torch.zeros(nc, D, device=DEV), torch.zeros(D, device=DEV)
+    _lib.check(k.lib.pm_vit_head_bwd(_ptr(dout) if head else None, None if head else _ptr(dout), _ptr(x), N, pool, _ptr(gamma),
+                                     _ptr(W) if head else None, _ptr(feat), _ptr(xhm), _ptr(mean), _ptr(rstd), None, None, 1,
+                                     _ptr(dW2) if head else None, None, _ptr(dg2), None, B, D, nc if head else 0, _stream()),
+               "vit_head_bwd frozen")
+    assert torch.equal(dg2, dg) and (not head or torch.equal(dW2, dW))
+
+
+@pytest.mark.parametrize("B,nc", [(64, 2), (7, 2), (300, 2), (9, 5), (700, 3)])
+def test_supervised_loss_op(B, nc, golden):
+    """pm_supervised_loss_fwd + pm_scale through ssl4polyp_amd.supervised_loss: value and gradient against torch's
+    BCEWithLogitsLoss(pos_weight) on l1 - l0 (two classes, tc.py:3347-3374,6090-6102) / CrossEntropyLoss(weight)
+    (tc.py:6104), and against the reference-generated bce values of tests/golden/tables.npz."""
+    import ssl4polyp_amd as A
+    logits = rnd(B, nc, seed=200, scale=2.0)
+    g = torch.Generator().manual_seed(201)
+    y = torch.randint(0, nc, (B,), generator=g).to(DEV)
+    lr = logits.clone().requires_grad_(True)
+    if nc == 2:
+        for pw in (None, 0.37, 2.5):
+            lh = logits.clone().requires_grad_(True)
+            got = A.supervised_loss(lh, y, pos_weight=pw)
+            want = F.binary_cross_entropy_with_logits(lr[:, 1] - lr[:, 0], y.float(),
+                                                      pos_weight=None if pw is None else torch.tensor(pw, device=DEV))
+            assert abs(got.item() - want.item()) < 2e-6 * max(1.0, abs(want.item()))
+            lr.grad = None
+            (3.0 * want).backward()
+            (3.0 * got).backward()
+            assert rel(lh.grad, lr.grad) < 1e-5
+    else:
+        w = (0.5 + torch.rand(nc, generator=g)).to(DEV)
+        for cw in (None, w):
+            lh = logits.clone().requires_grad_(True)
+            got = A.supervised_loss(lh, y, class_weights=cw)
+            want = F.cross_entropy(lr, y, weight=cw)
+            assert abs(got.item() - want.item()) < 2e-6 * max(1.0, abs(want.item()))
+            lr.grad = None
+            (0.5 * want).backward()
+            (0.5 * got).backward()
+            assert rel(lh.grad, lr.grad) < 1e-5
+    if (B, nc) == (64, 2):  # the reference-generated table
+        fx = golden("tables.npz")
+        z, t = torch.from_numpy(fx["bce/logits"]).to(DEV), torch.from_numpy(fx["bce/targets"]).to(DEV)
+        for pw in (1.0, 0.37, 2.5):
+            np.testing.assert_allclose(A.supervised_loss(z, t, pos_weight=pw).item(), fx[f"bce/pw{pw}"], rtol=2e-6)

@@ -68,7 +68,7 @@ def _worker(rank, world, port, q):
         imgs, labels = _batch(rank)
         launches = []
         orig = ddp.sync._launch
-        ddp.sync._launch = lambda t: (launches.append(t.numel()), orig(t))[1]
+        ddp.sync._launch = lambda r, lo, hi: (launches.append(hi - lo), orig(r, lo, hi))[1]
         params = _run_steps(model, ddp, opt, imgs.to(dev), labels.to(dev), 3, 1.0 / world)
         q.put((rank, {n: v.numpy() for n, v in params.items()}, len(launches)))  # by value (no fd passing)
     finally:
@@ -111,3 +111,62 @@ def test_two_rank_data_parallel_matches_single_process():
         print(f"{n:40s} {err:.3e}")
         worst = max(worst, err)
     assert worst < 2e-5, worst
+
+
+def _nccl_worker(port, q):
+    """world size 1 on the RCCL backend with the synchroniser forced on: the collectives really run on the side stream
+    (RCCL's Work.wait() is a stream-side wait, unlike gloo's host block) behind the autograd end-of-backward callback,
+    through a staged freeze schedule (linear probe -> head+1 -> full), with the overlapped AdamW."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from ssl4polyp_amd.optim import FusedAdamW
+        from ssl4polyp_amd.parallel import DataParallel
+        import ssl4polyp_amd as A
+        imgs, labels = _batch("all")
+        imgs, labels = imgs.to(dev), labels.to(dev)
+
+        def run(force):
+            model = _model("bf16")
+            ddp = DataParallel(model, dev, bucket_mb=0.05, force_sync=force)
+            assert (ddp.sync is not None) == force
+            opt = FusedAdamW(model, lr=1e-3, weight_decay=0.05, overlap_forward=True)
+            if force:
+                opt.grad_sync = ddp.sync
+            sent = []
+            for step in range(6):
+                mode = ["none", "none", "head+1", "head+1", "full", "full"][step]
+                for n, p in model.named_parameters():
+                    if "pos_embed" not in n:
+                        p.requires_grad_(mode == "full" or n.startswith("lin_head") or (mode == "head+1" and n.startswith("blocks.2.")))
+                opt.zero_grad(set_to_none=True)
+                loss = A.supervised_loss(ddp(imgs), labels.long(), pos_weight=1.0)
+                loss.backward()
+                opt.step()
+                if force:
+                    sent.append(4 * sum(hi - lo for _, lo, hi in ddp.sync.launched))
+            torch.cuda.synchronize()
+            return {n: p.detach().float().cpu().numpy() for n, p in model.named_parameters()}, sent, float(loss)
+
+        a, sent, la = run(True)
+        b, _, lb = run(False)
+        same = all((a[n] == b[n]).all() for n in a)
+        q.put((same, sent, la, lb))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world1_forced_sync_matches_unsynchronised_run():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    same, sent, la, lb = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    # a one-rank SUM all-reduce is the identity: the forced-sync run must equal the plain run bit for bit -- any missing
+    # fence between the RCCL stream, the wgrad side stream, the overlapped AdamW and the next forward would show here
+    assert same and la == lb
+    assert sent[0] == sent[1] == 4 * (128 + 64) and sent[1] < sent[2] == sent[3] < sent[4] == sent[5], sent

@@ -34,9 +34,19 @@ def test_library_exports_every_declared_symbol(built):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/polypmae.h but not exported"
     from ssl4polyp_amd import _lib
-    assert set(_lib.SIGNATURES) | {"pm_strerror", "pm_abi_version"} == set(names)
+    assert set(_lib.SIGNATURES) | {"pm_strerror", "pm_abi_version", "pm_gemm_workspace_bytes", "pm_workspace_bytes"} == set(names)
     handle = _lib.load()
-    assert handle.pm_abi_version() == 2
+    assert handle.pm_abi_version() == _lib.ABI_VERSION == 3
+    # nothing undeclared leaves the library: every exported pm_* symbol is in the header (diagnostic hooks included)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", built], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("pm_")}
+    assert exported == set(names), exported ^ set(names)
+    # workspace queries answer without a GPU: the split-K slabs of the ViT-B fc1 weight gradient on half of the CUs
+    opts = _lib.GemmOpts(128, 0)
+    assert handle.pm_gemm_workspace_bytes(1, 1, _lib.PM_BF16, 3072, 768, 12608, ctypes.byref(opts)) == 3 * 3072 * 768 * 4
+    assert handle.pm_gemm_workspace_bytes(0, 0, _lib.PM_BF16, 12608, 768, 768, None) == 0
+    assert handle.pm_workspace_bytes(_lib.WS_LAYERNORM_BWD, 12608, 768) == 1024 * 3 * 768 * 4
     assert handle.pm_strerror(-2).decode() == "unsupported shape"
 
 

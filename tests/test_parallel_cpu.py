@@ -40,9 +40,6 @@ def _worker(rank, world, port, bucket_mb, q):
             dist.all_reduce(t)
             want[r] = t
         sync = GradSync(rt, None, bucket_mb=bucket_mb)
-        launches = []
-        orig = sync._launch
-        sync._launch = lambda t: (launches.append(t.numel()), orig(t))[1]
         # the order in which the engine finishes gradients (models._MaeFn.backward)
         for i in reversed(range(2)):
             sync.block_done("decoder_blocks.", i)
@@ -51,7 +48,10 @@ def _worker(rank, world, port, bucket_mb, q):
         sync.backward_done(in_backward=False)
         sync.wait()
         ok = all(torch.equal(f.G[r], want[r]) for r in ("vec", "mat"))
-        covered = sum(launches[:-1]) == f.G["mat"].numel() and launches[-1] == f.G["vec"].numel()
+        launches = [hi - lo for _, lo, hi in sync.launched]
+        # every matrix is trainable; the frozen positional tables sit between trainable vectors and travel with them
+        covered = sum(launches[:-1]) == f.G["mat"].numel() and launches[-1] == f.G["vec"].numel() and \
+            [r for r, _, _ in sync.launched][-1] == "vec"
         # no_sync-style disable: nothing is launched
         sync.enabled = False
         before = f.G["mat"].clone()
@@ -82,6 +82,80 @@ def test_bucketed_allreduce_schedule_gloo(bucket_mb, min_launches):
         assert n >= min_launches
 
 
+def _freeze_worker(rank, world, port, q):
+    """Staged fine-tune schedule (finetune.py:49-126 via tc.py:924-953): none -> head+1 -> full.  The synchroniser must
+    follow the requires_grad flags: only trainable ranges are reduced, frozen ranges are left alone, the plan is rebuilt
+    exactly when the set changes."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ssl4polyp_amd as A
+        from ssl4polyp_amd.flat import FlatParams
+        from ssl4polyp_amd.parallel import GradSync
+        torch.manual_seed(0)
+        m = A.ViT_from_MAE(None, True, 2, False, None, embed_dim=64, depth=3, num_heads=2, out_token="cls")
+        rt = m._rt
+        rt.flat = FlatParams(m, torch.bfloat16)
+        rt.flat.materialize(torch.device("cpu"))
+        f = rt.flat
+        sync = GradSync(rt, None, bucket_mb=0.05, merge_gap=0)
+        out = []
+
+        def set_mode(mode):  # what configure_finetune_parameters does to the flags
+            for n, p in m.named_parameters():
+                if n in ("pos_embed", "decoder_pos_embed"):
+                    continue  # fixed sincos tables: never trainable (models_mae.py:37,51)
+                p.requires_grad_(mode == "full" or n.startswith("lin_head") or (mode == "head+1" and n.startswith("blocks.2.")))
+
+        for step, mode in enumerate(["none", "none", "head+1", "full", "full"]):
+            set_mode(mode)
+            g = torch.Generator().manual_seed(1000 * step + rank)
+            for r in ("vec", "mat"):
+                f.G[r].copy_(torch.randn(f.G[r].shape, generator=g))
+            mine = {r: f.G[r].clone() for r in ("vec", "mat")}
+            want = {}
+            for r in ("vec", "mat"):
+                t = f.G[r].clone()
+                dist.all_reduce(t)
+                want[r] = t
+            for i in reversed(range(3)):
+                sync.block_done("blocks.", i)
+            sync.backward_done(in_backward=False)
+            sync.wait()
+            good = True
+            for i, p in enumerate(f.params):
+                r, lo, n = f.region[i], f.offset[i], f.numel[i]
+                ref = want[r] if p.requires_grad else mine[r]  # reduced iff trainable, else untouched
+                good &= torch.equal(f.G[r][lo:lo + n], ref[lo:lo + n])
+            out.append((mode, good, 4 * sum(hi - lo for _, lo, hi in sync.launched), sync.trainable_bytes(), sync.plan_builds))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_freeze_aware_gradient_sync_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_freeze_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        modes = [o[0] for o in out]
+        assert modes == ["none", "none", "head+1", "full", "full"]
+        for mode, good, sent, trainable, builds in out:
+            assert good, f"rank {rank} {mode}: reduced / untouched ranges wrong"
+            assert sent == trainable, f"rank {rank} {mode}: sent {sent} B for {trainable} B of trainable gradients"
+        assert [o[4] for o in out] == [1, 1, 2, 3, 3]  # plan rebuilt only at the transitions
+        # linear probe: lin_head.weight (2 x 64 -> one 128-element segment) + lin_head.bias (one 64-element aligned segment)
+        assert out[0][2] == 4 * (128 + 64)
+        assert out[0][2] < out[2][2] < out[3][2]
+
+
 def _eval_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -95,7 +169,21 @@ def _eval_worker(rank, world, port, q):
         fwd = model.forward
         model.forward = lambda x: (seen.append(x.shape[0]), fwd(x))[1]
         lg, tg, pr = T.evaluate_cls(model, loader, "cpu", return_probs=True)
-        q.put((rank, lg.numpy(), tg.numpy(), pr.numpy(), len(seen)))
+        n_list = len(seen)
+        # a real DataLoader: the rank-local batch sampler must keep the dataset from ever producing foreign items
+        class Items(torch.utils.data.Dataset):
+            def __init__(self):
+                self.touched = []
+            def __len__(self):
+                return 23
+            def __getitem__(self, i):
+                self.touched.append(i)
+                gi = torch.Generator().manual_seed(i)
+                return torch.randn(3, 2, 2, generator=gi), torch.tensor(i)
+        ds = Items()
+        dl = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=0)
+        lg2, tg2 = T.evaluate_cls(model, dl, "cpu")
+        q.put((rank, lg.numpy(), tg.numpy(), pr.numpy(), n_list, sorted(ds.touched), tg2.numpy(), lg2.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -124,8 +212,13 @@ def test_sharded_evaluation_gloo():
     lg, tg, pr = T.evaluate_cls(model, loader, "cpu", return_probs=True)
     assert torch.allclose(pr, torch.sigmoid(lg[:, 1] - lg[:, 0]))
     for rank in (0, 1):
-        rl, rt, rp, n_fwd = res[rank]
+        rl, rt, rp, n_fwd, touched, tg2, lg2 = res[rank]
         assert n_fwd == (3 if rank == 0 else 2)  # batches 0,2,4 / 1,3
+        # DataLoader path: 23 items in batches of 4 -> rank 0 decodes batches 0,2,4 (items 0-3, 8-11, 16-19), rank 1 the
+        # others; nobody touches a foreign item, and both ranks hold all 23 results in dataset order
+        mine = [i for i in range(23) if (i // 4) % 2 == rank]
+        assert touched == mine, (rank, touched)
+        assert tg2.tolist() == list(range(23)) and lg2.shape == (23, 2)
         assert torch.equal(torch.from_numpy(rl), lg) and torch.equal(torch.from_numpy(rt), tg)
         assert torch.equal(torch.from_numpy(rp), pr)
     # multi-class: softmax
