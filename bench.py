@@ -304,10 +304,17 @@ def parity_block(workload, model, imgs, labels, precision):
             lo.backward()
             errs = {n: rel_l2(p.grad, leaves[n].grad) for n, p in model.named_parameters()
                     if p.grad is not None and leaves[n].grad is not None and not n.endswith("attn.qkv.bias")}
-            worst = max(errs, key=errs.get)
-            out.update(logits_max_rel=rel(logits, lr.detach()), loss_rel=rel(loss, lo.detach()),
-                       grad_rel_l2_worst=errs[worst], grad_rel_l2_worst_name=worst,
-                       grad_rel_l2_median=sorted(errs.values())[len(errs) // 2], grads_compared=len(errs))
+            mats = {n: e for n, e in errs.items() if leaves[n].ndim >= 2 and leaves[n].shape[0] > 1}
+            vecs = {n: e for n, e in errs.items() if n not in mats}
+            wm, wv = max(mats, key=mats.get), max(vecs, key=vecs.get)
+            out.update(logits_max_rel=rel(logits.detach(), lr.detach()), loss_rel=rel(loss.detach(), lo.detach()),
+                       weight_grad_rel_l2_worst=mats[wm], weight_grad_rel_l2_worst_name=wm,
+                       weight_grad_rel_l2_median=sorted(mats.values())[len(mats) // 2],
+                       vector_grad_rel_l2_worst=vecs[wv], vector_grad_rel_l2_worst_name=wv,
+                       vector_grad_rel_l2_median=sorted(vecs.values())[len(vecs) // 2], grads_compared=len(errs),
+                       note="vector gradients (biases, LayerNorm affine, tokens) are sums over all B x N tokens of "
+                            "bf16-stored activation gradients whose signs cancel: their relative error grows with the "
+                            "cancellation, not with a kernel's accuracy (fp32 mode: ~1e-6 on every parameter)")
         else:
             g = torch.Generator(device=imgs.device).manual_seed(4321)
             noise = torch.rand(imgs.shape[0], 196, device=imgs.device, generator=g)
@@ -410,6 +417,11 @@ def run_workload(args, workload, batch, device, world, rank, headline):
         from ssl4polyp_amd.data import DevicePrefetcher
         return DevicePrefetcher([host_pool[i % 4] for i in range(n)], device, flip_p=0.5, generator=host_gen)
 
+    parity = None
+    if rank == 0 and world == 1 and not args.no_parity:
+        # at the freshly initialised weights, before any optimizer step: after tens of AdamW steps at lr 1e-3 on random
+        # labels the network's outputs and gradients collapse towards zero and relative errors stop meaning anything
+        parity = parity_block(workload, model, imgs, labels, args.precision)
     if host_input:
         if use_graph:
             sys.exit("--input host feeds a new batch every step: use eager launch")
@@ -419,6 +431,15 @@ def run_workload(args, workload, batch, device, world, rank, headline):
         for _ in range(args.warmup):
             step()
     torch.cuda.synchronize()
+    # host cost of enqueueing a step, measured on an empty queue (inside the timed loop the host runs ahead until the
+    # HIP queue is full and is then throttled to the device's pace, so the loop's own enqueue time says nothing)
+    t_enq = float("nan")
+    if not host_input:
+        t_h = time.perf_counter()
+        for _ in range(3):
+            step()
+        t_enq = (time.perf_counter() - t_h) / 3
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -429,7 +450,6 @@ def run_workload(args, workload, batch, device, world, rank, headline):
     else:
         for _ in range(args.steps):
             loss = step()
-    t_enq = time.perf_counter() - t0  # the host has enqueued every step; the device may still be running
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -470,14 +490,14 @@ def run_workload(args, workload, batch, device, world, rank, headline):
             roof["hbm_kernels"] = hb        # in-step (beside the weight-gradient stream), algorithmic bytes / time
             roof["gemm_share_of_step"] = round(gt / (dt / args.steps), 3)
         rec = {"value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+               "host_enqueue_ms_per_step": round(t_enq * 1e3, 3),
                "config": {"workload": WORKLOAD_NAME[workload] + f", bs={batch}/GPU, 224^2, AdamW, random init",
                           "global_batch": batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "lr_schedule": "new lr every step" if args.lr_every_step else "constant"},
                "roofline": roof}
-        if world == 1 and not args.no_parity:
-            rec["parity"] = parity_block(workload, model, imgs, labels, args.precision)
+        if parity is not None:
+            rec["parity"] = parity
     del model, ddp, opt, eager_step, step
     torch.cuda.empty_cache()
     return rec

@@ -91,6 +91,30 @@ int pm_gemm_ex(const void* A, long lda, int a_kmajor, const void* B, long ldb, i
                const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
                int M, int N, int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, void* stream);
 
+/* Every weight gradient of one transformer block in ONE launch (autograd of timm Block's four Linears: attn.qkv,
+ * attn.proj, mlp.fc1, mlp.fc2 -- models_mae.py:39-41,53-55 through engine_pretrain.py:65 / tc.py:4533):
+ *   dW_i[n_out][n_in] (+)= dY_i^T X_i,   dY_i act [K][n_out] (lddy), X_i act [K][n_in] (ldx), K = number of tokens.
+ * The weight gradients have a huge reduction dimension and few output tiles; one GEMM at a time needs split-K (short
+ * k-loops, f32 slabs, a reduce launch each).  Grouped, the ~100 tiles of a ViT-B block each run their whole K in one
+ * workgroup: no slabs, no reduce, deterministic, and the launch occupies ~100 CUs beside the caller's dgrad chain.
+ * `items` is a HOST array of n <= 8 descriptors (copied into the kernel arguments).  Returns PM_ESHAPE when the group
+ * does not fit the ring kernel (f32 mode, K % 32 != 0, K < 2048, n_out < 256, n_in < 128): the caller then issues
+ * pm_gemm_ws per gradient. */
+typedef struct pm_wgrad_item {
+  const void* dY;
+  long lddy;
+  const void* X;
+  long ldx;
+  float* dW;
+  long lddw;
+  int n_out, n_in;
+  int accumulate; /* dW += (gradient accumulation) instead of dW = */
+  float* dbias;   /* optional f32 [n_out]: += column sums of dY = the Linear's bias gradient, computed beside the GEMM on
+                     the matrix cores (the dY fragments are already in registers) instead of by a separate pm_colsum pass */
+} pm_wgrad_item;
+/* max_blocks: workgroups (= CUs) the launch may occupy; 0 = one per tile.  Fewer workgroups walk several tiles each. */
+int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_dtype, int max_blocks, void* stream);
+
 /* pm_gemm that also accumulates the column sums of the stored result: colsum[n] += sum_m C[m][n] (f32 [N]) -- the bias
  * gradient of the Linear whose output gradient C is (reference: autograd of nn.Linear, e.g. Mlp.fc1.bias.grad from the
  * dGELU dgrad).  Fused into the epilogue where the kernel in use supports it (act-typed C of the large-tile kernel;

@@ -24,6 +24,7 @@ SIGNATURES = {
     "pm_gemm": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P],
     "pm_gemm_ws": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P],
     "pm_gemm_ex": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P, P],
+    "pm_wgrad_group": [P, I, I, I, I, P],
     "pm_gemm_colsum": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, P, I, I, I, P, ctypes.c_size_t, P],
     "pm_attention_fwd": [P, P, P, I, I, I, I, I, P],
     "pm_attention_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
@@ -62,6 +63,13 @@ class GemmOpts(ctypes.Structure):
     _fields_ = [("max_blocks", c_int), ("variant", c_int)]
 
 
+class WgradItem(ctypes.Structure):
+    """pm_wgrad_item of include/polypmae.h."""
+    _fields_ = [("dY", c_void_p), ("lddy", c_long), ("X", c_void_p), ("ldx", c_long), ("dW", c_void_p), ("lddw", c_long),
+                ("n_out", c_int), ("n_in", c_int), ("accumulate", c_int), ("dbias", c_void_p)]
+
+
+PM_ESHAPE = -2
 _lib = None
 
 

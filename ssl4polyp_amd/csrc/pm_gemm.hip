@@ -59,6 +59,7 @@ struct GemmArgs {
   int split_k;       // >1: blockIdx.y = split, C = f32 slabs [split][M][ldc]
   int ksteps_split;  // k-steps per split
   float* cs_partials;  // pm_gemm_colsum: per (row tile, wave row) column sums of the result [tiles_m * WM][N], or NULL
+  float* xsum;         // grouped wgrad: xsum[m] += sum_k X(m, k) (= the bias gradient: column sums of dY), or NULL
 #ifdef PM_GEMM_STAMP
   unsigned long long* stamps;  // diagnostic build only: per-wave cycle sums of the k-loop segments
 #endif
@@ -576,9 +577,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "add the immediate");
 }
 
-template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false, int NW = 8,
-          bool SWP = false>
-__global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
+// One block = one BM_ x BN_ output tile (`tile` = row-major tile index, `split_idx` = k-slice for split-K).  The body of
+// gemm_v3_kernel (one GEMM per launch) and of wgrad_group_kernel (the weight gradients of a whole transformer block in
+// one launch, full-K tiles).
+template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, bool DIRECT, bool PP, bool XK, int NW, bool SWP,
+          bool XSUM = false>
+__device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const int split_idx) {
   constexpr int TM = BM_ / WM, TN = BN_ / WN;      // per-wave tile
   constexpr int MT = TM / 32, NTL = TN / 32;       // 32x32 accumulators per wave
   constexpr int XB = BM_ * 64, WB = BN_ * 64;      // bytes per stage per side
@@ -606,19 +610,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
     }
   };
 #endif
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = tile / a.tiles_n, tn = tile % a.tiles_n;
   const int m0 = tm * BM_, n0 = tn * BN_;
   const __bf16* X = reinterpret_cast<const __bf16*>(a.X);
   const __bf16* W = reinterpret_cast<const __bf16*>(a.W);
   int nk = a.K / V3_KE;
   if (a.split_k > 1) {  // split-K: this block owns k-steps [kbeg, kend) and writes an f32 partial slab
-    const int kbeg = blockIdx.y * a.ksteps_split;
+    const int kbeg = split_idx * a.ksteps_split;
     const int kend = (kbeg + a.ksteps_split) < nk ? (kbeg + a.ksteps_split) : nk;
     nk = kend - kbeg;
     X += XK ? (long)kbeg * V3_KE * a.ldx : (long)kbeg * V3_KE;
     W += WK ? (long)kbeg * V3_KE * a.ldw : (long)kbeg * V3_KE;
-    a.C = reinterpret_cast<float*>(a.C) + (long)blockIdx.y * a.M * a.ldc;
+    a.C = reinterpret_cast<float*>(a.C) + (long)split_idx * a.M * a.ldc;
   }
 
   f32x16 acc[NTL][MT];
@@ -628,6 +631,25 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
     for (int j = 0; j < MT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Row sums of the X operand beside the GEMM (grouped weight gradients: X = dY^T, so xsum = the Linear's bias gradient).
+  // The 32x32x16 X fragment (lane l: row l&31, k-half l>>5) is fed as the B operand of a 16x16x32 MFMA, which reads it as
+  // column l&15, k-group l>>4: rows r and r+16 of the fragment fall on the same column in k-groups {0,2} / {1,3}.  An A
+  // operand that is all ones in row 0 for k-groups {0,2} and in row 1 for k-groups {1,3} (lanes 0, 32 / 17, 49) therefore
+  // yields D[0][c] = sum_k X[c][k], D[1][c] = sum_k X[16+c][k]: lane c < 16 holds them in registers 0 and 1.
+  // 2*MT extra 16-cycle MFMAs per k-step, only in the waves of column 0 of the tiles of column 0 (each row once).
+  static_assert(!XSUM || (XK && !SWP), "row sums ride on the k-major X fragments of the ping-pong / plain loops");
+  f32x4 xs[MT];
+  Frag16 ones_sel;
+  bool do_xsum = false;
+  if constexpr (XSUM) {
+    do_xsum = a.xsum != nullptr && tn == 0 && wn == 0;
+    const bool one = lane == 0 || lane == 32 || lane == 17 || lane == 49;
+    const unsigned v = one ? 0x3F803F80u : 0u;  // two bf16 1.0
+    ones_sel.u = u32x4{v, v, v, v};
+#pragma unroll
+    for (int j = 0; j < MT; ++j) xs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   auto issue = [&](int t) {
     char* buf = smem + (t % STAGES) * SB;
@@ -662,6 +684,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < MT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][i].h, fx[kk][j].h, acc[i][j], 0, 0, 0);
+    if constexpr (XSUM) {
+      if (do_xsum) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int j = 0; j < MT; ++j)
+            xs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_sel.h, fx[kk][j].h, xs[j], 0, 0, 0);
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -868,6 +899,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
 #ifdef PM_GEMM_STAMP
   stamp_loop_end = __builtin_readcyclecounter();
 #endif
+  if constexpr (XSUM) {
+    if (do_xsum && lane < 16) {  // one wave per row range: plain read-modify-write, fixed order
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int m = m0 + wm * TM + 32 * j + lane;
+        if (m < a.M) a.xsum[m] += xs[j][0];
+        if (m + 16 < a.M) a.xsum[m + 16] += xs[j][1];
+      }
+    }
+  }
   const int h = lane >> 5;
   const int epi = a.epilogue;
   if constexpr (DIRECT) {
@@ -1080,6 +1121,63 @@ __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
 #endif
 }
 
+template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false, int NW = 8,
+          bool SWP = false>
+__global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
+  gemm_v3_tile<BM_, BN_, WM, WN, WK, STAGES, DIRECT, PP, XK, NW, SWP>(a, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// grouped weight gradients: every dW of one transformer block in ONE launch, one full-K tile per workgroup
+// ------------------------------------------------------------------------------------------------
+// The weight gradients have a huge reduction dimension (K = number of tokens: 12 608 ... 50 432) and few output tiles
+// (ViT-B: 27 + 9 + 36 + 36 tiles of 256x256).  One GEMM per launch therefore needs split-K to fill the chip: short
+// k-loops, f32 slabs written and re-read, a reduce launch each -- and the prologue / epilogue paid per slice.  Grouping
+// the four gradients of a block gives ~108 independent tiles at once: each workgroup runs ONE tile over the whole K
+// (394+ k-steps: prologue and epilogue vanish, no slabs, no reduce, the result is deterministic by construction) and the
+// launch takes ~100 CUs, which is the share the engine wants to give the weight-gradient stream beside the dgrad chain.
+constexpr int kMaxGroup = 8;
+struct WgradProb {
+  const void* dY;     // [K][M]  (tokens x out features: the Linear's output gradient as stored)
+  const void* X;      // [K][N]  (tokens x in features: the Linear's input as stored)
+  float* dW;          // [M][N]
+  long lddy, ldx, lddw;
+  int M, N;           // out features, in features
+  int tiles_n;
+  int tile_begin;     // first global tile id of this problem
+  int accumulate;     // dW += instead of dW =
+  float* dbias;       // [M] += column sums of dY (the Linear's bias gradient), or NULL
+};
+struct WgradGroupArgs {
+  WgradProb p[kMaxGroup];
+  int n, K, total_tiles;
+};
+
+template <int BM_, int BN_, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroupArgs g) {
+  // gridDim.x workgroups (a multiple of 8, or total_tiles) walk the tiles t = blockIdx.x, + gridDim.x, ...: the caller
+  // chooses how many CUs the weight-gradient stream takes from the dgrad chain beside it.  xcd_remap gives every XCD a
+  // contiguous run of tile ids (same dY panel -> same private L2); with gridDim.x % 8 == 0 a workgroup stays on its XCD's run.
+  for (int t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
+    const int tile = xcd_remap(t, g.total_tiles);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroup; ++i)
+      if (i < g.n && tile >= g.p[i].tile_begin) pi = i;
+    const WgradProb& pr = g.p[pi];
+    GemmArgs a;
+    a.X = pr.dY; a.W = pr.X; a.ldx = pr.lddy; a.ldw = pr.ldx; a.bias = nullptr; a.C = pr.dW; a.ldc = pr.lddw; a.aux = nullptr;
+    a.resid = nullptr; a.M = pr.M; a.N = pr.N; a.K = g.K; a.epilogue = pr.accumulate ? PM_EPI_ACCUM : PM_EPI_STORE;
+    a.c_dtype = PM_F32; a.tiles_m = 0; a.tiles_n = pr.tiles_n; a.split_k = 1; a.ksteps_split = 0; a.cs_partials = nullptr;
+    a.xsum = pr.dbias;
+#ifdef PM_GEMM_STAMP
+    a.stamps = nullptr;
+#endif
+    gemm_v3_tile<BM_, BN_, WM, WN, true, 4, true, true, true, 8, false, true>(a, tile - pr.tile_begin, 0);
+    __syncthreads();  // every wave is done with the LDS ring before the next tile's first stages are issued
+  }
+}
+
 template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, int NW = 8, bool SWP = false>
 int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   a.tiles_m = (a.M + BM_ - 1) / BM_;
@@ -1285,6 +1383,7 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
   a.tiles_n = (N + BN - 1) / BN;
   a.split_k = 1;
   a.cs_partials = nullptr;
+  a.xsum = nullptr;
 #ifdef PM_GEMM_STAMP
   a.stamps = g_stamps;
 #endif
@@ -1418,4 +1517,56 @@ extern "C" int pm_gemm(const void* A, long lda, int a_kmajor, const void* B, lon
                        int M, int N, int K, void* stream) {
   return pm_gemm_ws(A, lda, a_kmajor, B, ldb, b_kmajor, in_dtype, bias, C, ldc, c_dtype, epilogue, aux, resid, M, N, K,
                     nullptr, 0, stream);
+}
+
+extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_dtype, int max_blocks, void* stream) {
+  if (!items || n <= 0) return PM_EINVAL;
+  if (n > kMaxGroup || K <= 0) return PM_ESHAPE;
+  if (in_dtype != PM_BF16) return PM_ESHAPE;              // (f32 mode keeps the per-GEMM split-K path)
+  if ((K % V3_KE) != 0 || K < 2048) return PM_ESHAPE;     // ring kernel: whole 32-element k-steps, long reduction
+  long t256 = 0;
+  for (int i = 0; i < n; ++i) {
+    const pm_wgrad_item& it = items[i];
+    if (!it.dY || !it.X || !it.dW) return PM_EINVAL;
+    if (it.n_out < 256 || it.n_in < 128) return PM_ESHAPE;
+    if ((it.n_out & 7) || (it.n_in & 7) || (it.lddy & 7) || (it.ldx & 7) || (it.lddw & 3)) return PM_EALIGN;
+    if (((uintptr_t)it.dY & 15) || ((uintptr_t)it.X & 15) || ((uintptr_t)it.dW & 15)) return PM_EALIGN;
+    t256 += (long)((it.n_out + 255) / 256) * ((it.n_in + 255) / 256);
+  }
+  // 256x256 tiles (twice the MFMAs per barrier, 128 FLOP per LDS-fill byte) when they still give >= 64 workgroups;
+  // otherwise 256x128 (the 512-wide MAE decoder: 48 -> 96 workgroups)
+  const int bn = t256 >= 64 ? 256 : 128;
+  WgradGroupArgs g;
+  g.n = n; g.K = K;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const pm_wgrad_item& it = items[i];
+    WgradProb& p = g.p[i];
+    p.dY = it.dY; p.X = it.X; p.dW = it.dW; p.lddy = it.lddy; p.ldx = it.ldx; p.lddw = it.lddw;
+    p.M = it.n_out; p.N = it.n_in; p.accumulate = it.accumulate ? 1 : 0; p.dbias = it.dbias;
+    p.tiles_n = (it.n_in + bn - 1) / bn;
+    p.tile_begin = total;
+    total += ((it.n_out + 255) / 256) * p.tiles_n;
+  }
+  for (int i = n; i < kMaxGroup; ++i) g.p[i] = g.p[0];
+  g.total_tiles = total;
+  int grid = total;
+  if (max_blocks > 0 && max_blocks < total) {
+    grid = (max_blocks / 8) * 8;  // whole XCD rounds: a workgroup keeps walking its own XCD's run of tiles
+    if (grid < 8) grid = 8;
+    if (grid > total) grid = total;
+  }
+  hipStream_t s = pm_stream(stream);
+  if (bn == 256) {
+    auto kern = wgrad_group_kernel<256, 256, 2, 4>;
+    constexpr int ring = 4 * (256 + 256) * 64;
+    PM_ALLOW_LDS(kern, ring);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ring, s, g);
+  } else {
+    auto kern = wgrad_group_kernel<256, 128, 4, 2>;
+    constexpr int ring = 4 * (256 + 128) * 64;
+    PM_ALLOW_LDS(kern, ring);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ring, s, g);
+  }
+  return pm_check_launch();
 }

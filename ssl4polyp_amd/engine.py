@@ -149,6 +149,30 @@ class Kernels:
         """dx[M,K_in] = dy[M,N_out] @ W[N_out,K_in]  (W read as stored: k-major B operand); colsum += column sums of dx."""
         self.gemm(dy, N_out, 0, W, K_in, 1, None, dx, K_in, epilogue, M, K_in, N_out, aux=aux, colsum=colsum)
 
+    GROUP_WGRAD = os.environ.get("PM_GROUP_WGRAD", "1") != "0"  # A/B switch: one grouped weight-gradient launch per block
+    GROUP_BLOCKS = int(os.environ.get("PM_GROUP_BLOCKS", "0"))  # CUs the grouped launch may take (0 = one workgroup per tile)
+    GROUP_BIAS = os.environ.get("PM_GROUP_BIAS", "1") != "0"    # qkv / fc1 bias gradients inside that launch (no pm_colsum pass)
+
+    def wgrad_group(self, items, K) -> bool:
+        """items: [(dy [K, n_out], x [K, n_in], dW f32 [n_out, n_in], accumulate[, dbias f32 [n_out] (+=)])].  One launch for all
+        (pm_wgrad_group); False when the shapes do not fit the grouped kernel (the caller then uses linear_wgrad)."""
+        n = len(items)
+        arr = (_lib.WgradItem * n)()
+        for j, (dy, x, dW, acc, *rest) in enumerate(items):
+            n_out, n_in = dW.shape
+            arr[j] = _lib.WgradItem(_ptr(dy), n_out, _ptr(x), n_in, _ptr(dW), n_in, n_out, n_in, int(bool(acc)),
+                                    _ptr(rest[0]) if rest and rest[0] is not None else None)
+        st = self.lib.pm_wgrad_group(arr, n, K, _lib.dtype_code(items[0][0].dtype), self.GROUP_BLOCKS, _stream())
+        if st == _lib.PM_ESHAPE:
+            return False
+        _lib.check(st, "pm_wgrad_group")
+        return True
+
+    def can_group_wgrad(self, K: int, dims) -> bool:
+        """Same admission test as pm_wgrad_group (bf16, whole 32-token k-steps, long K, tiles of at least 256 x 128)."""
+        return (self.GROUP_WGRAD and self.precision == "bf16" and K % 32 == 0 and K >= 2048 and
+                all(o >= 256 and i >= 128 and o % 8 == 0 and i % 8 == 0 for o, i in dims))
+
     def linear_wgrad(self, dy, x, dW, M, N_out, K_in, accumulate):
         """dW[N_out,K_in] (+)= dy[M,N_out]^T @ x[M,K_in]  (both operands k-major, f32 output)."""
         self.gemm(dy, N_out, 1, x, K_in, 1, None, dW, K_in, EPI_ACCUM if accumulate else EPI_STORE, N_out, K_in, M)
@@ -350,8 +374,11 @@ class BlockStack:
                 ev.record(main)
                 side.wait_event(ev)
 
+            # One grouped launch for the block's four weight gradients (full-K tiles, no split-K slabs), issued once the
+            # whole dgrad chain of the block is enqueued; it runs beside block i-1's chain.
+            grouped = tr and k.can_group_wgrad(M, ((D, Hd), (Hd, D), (D, D), (3 * D, D)))
             # ---- MLP branch ----
-            if tr:
+            if tr and not grouped:
                 fork()
                 with torch.cuda.stream(side):
                     k.linear_wgrad(dx_act, bw.h_act, gr["mlp.fc2.weight"], M, D, Hd, accumulate("mlp.fc2.weight", i))
@@ -362,15 +389,16 @@ class BlockStack:
             if tr:
                 fork()
                 with torch.cuda.stream(side):
-                    k.linear_wgrad(d_hidden, bw.ln2, gr["mlp.fc1.weight"], M, Hd, D, accumulate("mlp.fc1.weight", i))
-                    if not fuse_cs:
+                    if not grouped:
+                        k.linear_wgrad(d_hidden, bw.ln2, gr["mlp.fc1.weight"], M, Hd, D, accumulate("mlp.fc1.weight", i))
+                    if not fuse_cs and not (grouped and k.GROUP_BIAS):
                         k.colsum(d_hidden, gr["mlp.fc1.bias"], M, Hd)
             k.linear_dgrad(d_hidden, p["mlp.fc1.weight"], ws.d_ln, M, Hd, D)
             k.layernorm_bwd(ws.d_ln, bw.x_mid, p["norm2.weight"], bw.mean2, bw.rstd2, dx, dmid, dmid_act,
                             gr["norm2.weight"] if tr else None, gr["norm2.bias"] if tr else None,
                             gr["attn.proj.bias"] if tr else None, M, D)
             # ---- attention branch ----
-            if tr:
+            if tr and not grouped:
                 fork()
                 with torch.cuda.stream(side):
                     k.linear_wgrad(dmid_act, bw.attn, gr["attn.proj.weight"], M, D, D, accumulate("attn.proj.weight", i))
@@ -379,8 +407,20 @@ class BlockStack:
             if tr:
                 fork()
                 with torch.cuda.stream(side):
-                    k.linear_wgrad(d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, accumulate("attn.qkv.weight", i))
-                    k.colsum(d_qkv, gr["attn.qkv.bias"], M, 3 * D)
+                    gb = grouped and k.GROUP_BIAS  # bias gradients (column sums of dY) inside the grouped launch
+                    if not gb:
+                        k.colsum(d_qkv, gr["attn.qkv.bias"], M, 3 * D)
+                    if grouped:
+                        ok = k.wgrad_group([(dx_act, bw.h_act, gr["mlp.fc2.weight"], accumulate("mlp.fc2.weight", i)),
+                                            (d_hidden, bw.ln2, gr["mlp.fc1.weight"], accumulate("mlp.fc1.weight", i),
+                                             gr["mlp.fc1.bias"] if (gb and not fuse_cs) else None),
+                                            (dmid_act, bw.attn, gr["attn.proj.weight"], accumulate("attn.proj.weight", i)),
+                                            (d_qkv, bw.ln1, gr["attn.qkv.weight"], accumulate("attn.qkv.weight", i),
+                                             gr["attn.qkv.bias"] if gb else None)], M)
+                        if not ok:
+                            raise _lib.PolypMaeError("pm_wgrad_group refused a group that can_group_wgrad admitted")
+                    else:
+                        k.linear_wgrad(d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, accumulate("attn.qkv.weight", i))
                     # no join here: the main stream runs on into block i-1 and waits for this event only before
                     # block i-2.  The block's matrix gradients are final in side-stream order.
                     pending[i] = torch.cuda.Event()

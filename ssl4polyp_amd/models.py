@@ -377,7 +377,10 @@ def supervised_loss(logits: torch.Tensor, targets: torch.Tensor, pos_weight=None
             raise ValueError("class_weights must have one entry per class")
     if logits.ndim != 2 or logits.shape[1] < 2:
         raise ValueError("supervised_loss expects logits [B, n_class >= 2]")
-    return _SupervisedLossFn.apply(logits, targets, pos_weight, class_weights)
+    if not logits.is_cuda:
+        raise _lib.PolypMaeError("supervised_loss runs on the MI355X HIP path only (got a CPU tensor)")
+    from . import ops  # noqa: F401  (registers torch.ops.polypmae.*)
+    return torch.ops.polypmae.supervised_loss(logits, targets, pos_weight, class_weights)
 
 
 class _MaeFn(torch.autograd.Function):
@@ -623,8 +626,8 @@ class MaskedAutoencoderViT(nn.Module):
         assert imgs.shape[2] == self.patch_embed.img_size[0] and imgs.shape[3] == self.patch_embed.img_size[1]
         if noise is None:
             noise = torch.rand(imgs.shape[0], self.patch_embed.num_patches, device=imgs.device)
-        names = rt.flat.names
-        return _MaeFn.apply(rt, imgs, noise, float(mask_ratio), names, *rt.flat.params)
+        from . import ops  # registers torch.ops.polypmae.* on first use
+        return torch.ops.polypmae.mae_forward(imgs, noise, float(mask_ratio), ops.register_runtime(rt), list(rt.flat.params))
 
 
 def mae_vit_base_patch16_dec512d8b(**kwargs):
@@ -668,7 +671,9 @@ class _ClassifierBase(nn.Module):
         rt = self._rt
         rt.ensure(imgs.device)
         assert imgs.shape[2] == self.patch_embed.img_size[0] and imgs.shape[3] == self.patch_embed.img_size[1]
-        return _VitClsFn.apply(rt, imgs, 1 if self.out_token == "spatial" else 0, head, rt.flat.names, *rt.flat.params)
+        from . import ops  # registers torch.ops.polypmae.* on first use
+        return torch.ops.polypmae.vit_forward(imgs, ops.register_runtime(rt), 1 if self.out_token == "spatial" else 0, head,
+                                              list(rt.flat.params))
 
 
 class ViT_from_MAE(_ClassifierBase):

