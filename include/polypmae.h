@@ -115,11 +115,10 @@ typedef struct pm_wgrad_item {
 /* max_blocks: workgroups (= CUs) the launch may occupy; 0 = one per tile.  Fewer workgroups walk several tiles each. */
 int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_dtype, int max_blocks, void* stream);
 
-/* pm_gemm that also accumulates the column sums of the stored result: colsum[n] += sum_m C[m][n] (f32 [N]) -- the bias
- * gradient of the Linear whose output gradient C is (reference: autograd of nn.Linear, e.g. Mlp.fc1.bias.grad from the
- * dGELU dgrad).  Fused into the epilogue where the kernel in use supports it (act-typed C of the large-tile kernel;
- * per-tile partial rows in `workspace`, reduced in a fixed order), otherwise pm_colsum_ws runs after the GEMM on the
- * same stream.  No split-K on this entry point (dgrad / forward shapes). */
+/* pm_gemm followed by the column sums of the stored result: colsum[n] += sum_m C[m][n] (f32 [N]) -- the bias gradient of
+ * the Linear whose output gradient C is (reference: autograd of nn.Linear).  Convenience composition (pm_gemm_ws +
+ * pm_colsum_ws on the same stream; `workspace` is the column sum's).  The training engine does not use it: the bias
+ * gradients of a block ride on pm_wgrad_group (dbias) and on pm_layernorm_bwd (dcolsum). */
 int pm_gemm_colsum(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
                    const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
                    float* colsum, int M, int N, int K, void* workspace, size_t ws_bytes, void* stream);

@@ -58,7 +58,6 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int split_k;       // >1: blockIdx.y = split, C = f32 slabs [split][M][ldc]
   int ksteps_split;  // k-steps per split
-  float* cs_partials;  // pm_gemm_colsum: per (row tile, wave row) column sums of the result [tiles_m * WM][N], or NULL
   float* xsum;         // grouped wgrad: xsum[m] += sum_k X(m, k) (= the bias gradient: column sums of dY), or NULL
 #ifdef PM_GEMM_STAMP
   unsigned long long* stamps;  // diagnostic build only: per-wave cycle sums of the k-loop segments
@@ -921,11 +920,6 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
       long noff8[NV8];
       bool nok8[NV8];
       f32x4 b0[NV8], b1[NV8];
-      float cs[NV8][8];
-#pragma unroll
-      for (int e = 0; e < NV8; ++e)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cs[e][k] = 0.f;
 #pragma unroll
       for (int i = 0; i < NTL; ++i)
 #pragma unroll
@@ -966,33 +960,6 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
             ok[p] = mok && nok8[e];
           }
           epilogue_batch8<2>(a, epi, off, ok, lo, hi);
-          if (a.cs_partials && mok) {  // column sums of what was stored (rows beyond M hold a clamped duplicate)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                cs[i * 2 + p][k] += lo[p][k];
-                cs[i * 2 + p][4 + k] += hi[p][k];
-              }
-          }
-        }
-      }
-      if (a.cs_partials) {
-        // sum over the 32 rows held by the lanes of each half-wave, then one 32-B row segment per (half, vector)
-        float* dst = a.cs_partials + (long)(tm * WM + wm) * a.N;
-#pragma unroll
-        for (int e = 0; e < NV8; ++e) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            float v = cs[e][k];
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
-            cs[e][k] = v;
-          }
-          if ((lane & 31) == 0 && nok8[e]) {
-            *reinterpret_cast<f32x4*>(dst + noff8[e]) = f32x4{cs[e][0], cs[e][1], cs[e][2], cs[e][3]};
-            *reinterpret_cast<f32x4*>(dst + noff8[e] + 4) = f32x4{cs[e][4], cs[e][5], cs[e][6], cs[e][7]};
-          }
         }
       }
 #ifdef PM_GEMM_STAMP
@@ -1168,7 +1135,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroupArgs g) {
     GemmArgs a;
     a.X = pr.dY; a.W = pr.X; a.ldx = pr.lddy; a.ldw = pr.ldx; a.bias = nullptr; a.C = pr.dW; a.ldc = pr.lddw; a.aux = nullptr;
     a.resid = nullptr; a.M = pr.M; a.N = pr.N; a.K = g.K; a.epilogue = pr.accumulate ? PM_EPI_ACCUM : PM_EPI_STORE;
-    a.c_dtype = PM_F32; a.tiles_m = 0; a.tiles_n = pr.tiles_n; a.split_k = 1; a.ksteps_split = 0; a.cs_partials = nullptr;
+    a.c_dtype = PM_F32; a.tiles_m = 0; a.tiles_n = pr.tiles_n; a.split_k = 1; a.ksteps_split = 0;
     a.xsum = pr.dbias;
 #ifdef PM_GEMM_STAMP
     a.stamps = nullptr;
@@ -1250,29 +1217,6 @@ int launch_glds(const GemmArgs& a, int xk, int wk, hipStream_t s) {
   return pm_check_launch();
 }
 
-// pm_gemm_colsum -> dispatcher hand-off: the dispatcher fuses the column sums into the register epilogue of the
-// large-tile kernel when it picks that kernel (and the partial rows fit), and reports how many partial rows it wrote.
-struct ColsumRequest {
-  float* partials = nullptr;
-  size_t capacity = 0;  // bytes
-  int rows = 0;         // out: partial rows written (0 = not fused)
-};
-
-// out[n] += sum over the partial rows, fixed order
-__global__ __launch_bounds__(1024) void gemm_colsum_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out,
-                                                                  int rows, int N) {
-  __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + lane;
-  red[rg][lane] = n < N ? strided_sum<8>(partials + n, N, rg, 16, rows) : 0.f;
-  __syncthreads();
-  if (rg == 0 && n < N) {
-    float t = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) t += red[g][lane];
-    out[n] += t;
-  }
-}
 // Split-K plan of a weight-gradient GEMM on the ring kernel (shared by the dispatcher and pm_gemm_workspace_bytes).
 // 256x256 tiles (twice the MFMAs per barrier) from 2x2 tiles up: ViT-B qkv / fc1 / fc2 gradients 74 us vs 83 with
 // 256x128; the MAE decoder's 512-wide gradients (K = 50 432 tokens) +2.8 % step rate; neutral for 768x768.
@@ -1302,7 +1246,7 @@ inline bool wgrad_ring_shape(int in_dtype, int a_kmajor, int b_kmajor, int M, in
 
 int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
                   const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid, int M, int N,
-                  int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, ColsumRequest* cs_req, void* stream);
+                  int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, void* stream);
 
 }  // namespace
 
@@ -1336,29 +1280,27 @@ extern "C" int pm_gemm_ex(const void* A, long lda, int a_kmajor, const void* B, 
                           const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid,
                           int M, int N, int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, void* stream) {
   return gemm_dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, in_dtype, bias, C, ldc, c_dtype, epilogue, aux, resid, M, N, K,
-                       workspace, ws_bytes, opts, nullptr, stream);
+                       workspace, ws_bytes, opts, stream);
 }
 
 extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
                           const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux,
                           const float* resid, int M, int N, int K, void* workspace, size_t ws_bytes, void* stream) {
   return gemm_dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, in_dtype, bias, C, ldc, c_dtype, epilogue, aux, resid, M, N, K,
-                       workspace, ws_bytes, nullptr, nullptr, stream);
+                       workspace, ws_bytes, nullptr, stream);
 }
 
 namespace {
 
 int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
                   const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid, int M, int N,
-                  int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, ColsumRequest* cs_req, void* stream) {
+                  int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, void* stream) {
   // per-call options (no process-wide state): kernel variant override (tuning scripts, tests) and the number of
   // workgroups a split-K weight gradient may spread over
   const int force_cfg = opts ? opts->variant : 0;
   int wgrad_blocks = (opts && opts->max_blocks > 0) ? opts->max_blocks : 256;
   if (wgrad_blocks < 16) wgrad_blocks = 16;
   if (wgrad_blocks > 1024) wgrad_blocks = 1024;
-  ColsumRequest cs_none;
-  ColsumRequest& cs = cs_req ? *cs_req : cs_none;
   if (!A || !B || !C) return PM_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return PM_ESHAPE;
   if (in_dtype != PM_BF16 && in_dtype != PM_F32) return PM_EINVAL;
@@ -1382,7 +1324,6 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
   a.tiles_m = (M + BM - 1) / BM;
   a.tiles_n = (N + BN - 1) / BN;
   a.split_k = 1;
-  a.cs_partials = nullptr;
   a.xsum = nullptr;
 #ifdef PM_GEMM_STAMP
   a.stamps = g_stamps;
@@ -1412,14 +1353,6 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
         if (epilogue == PM_EPI_RESIDUAL && !b_kmajor) cfg = cfg == 10 ? 26 : 25;
       }
     }
-    if ((cfg == 9 || cfg == 10) && cs.partials && c_dtype == PM_BF16 && (N & 7) == 0 && (ldc & 7) == 0 &&
-        (epilogue == PM_EPI_STORE || epilogue == PM_EPI_DGELU)) {
-      const int rows = ((M + (cfg == 9 ? 255 : 191)) / (cfg == 9 ? 256 : 192)) * 2;  // tiles_m x WM
-      if ((size_t)rows * N * sizeof(float) <= cs.capacity) {
-        a.cs_partials = cs.partials;
-        cs.rows = rows;
-      }
-    }
     switch (cfg) {
       case 6: return launch_v3<256, 256, 2, 4, 4, 2, true>(a, b_kmajor, s);          // plain ring loop, register epilogue
       case 8: return launch_v3<256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);   // ping-pong, LDS-staged epilogue
@@ -1431,6 +1364,10 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
       case 26: return launch_v3<192, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);
       // two 4-wave blocks per CU (128x256 tiles, 3-slot ring): measured slower everywhere, kept for the record
       case 27: return launch_v3<128, 256, 2, 2, 3, 2, false, false, 4, true>(a, b_kmajor, s);
+      // two 8-wave blocks per CU (64x64 per wave, <= 128 VGPRs, 3-slot ring = 72 KiB): one block's prologue / epilogue
+      // under the other's k-loop, at 85 instead of 128 FLOP per LDS-fill byte
+      case 28: return launch_v3<256, 128, 4, 2, 3, 4, true>(a, b_kmajor, s);
+      case 29: return launch_v3<128, 256, 2, 4, 3, 4, true>(a, b_kmajor, s);
       default: return launch_v3<256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
     }
   }
@@ -1497,18 +1434,9 @@ extern "C" int pm_gemm_colsum(const void* A, long lda, int a_kmajor, const void*
                               const float* resid, float* colsum, int M, int N, int K, void* workspace, size_t ws_bytes,
                               void* stream) {
   if (!colsum) return PM_EINVAL;
-  ColsumRequest req;
-  req.partials = reinterpret_cast<float*>(workspace);
-  req.capacity = workspace ? ws_bytes : 0;
   const int st = gemm_dispatch(A, lda, a_kmajor, B, ldb, b_kmajor, in_dtype, bias, C, ldc, c_dtype, epilogue, aux, resid, M, N, K,
-                               nullptr, 0, nullptr, &req, stream);
-  const int rows = req.rows;
+                               nullptr, 0, nullptr, stream);
   if (st) return st;
-  if (rows > 0) {
-    hipLaunchKernelGGL(gemm_colsum_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, pm_stream(stream),
-                       reinterpret_cast<const float*>(workspace), colsum, rows, N);
-    return pm_check_launch();
-  }
   return pm_colsum_ws(C, ldc, c_dtype, colsum, M, N, workspace, ws_bytes, stream);
 }
 

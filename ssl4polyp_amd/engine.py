@@ -76,7 +76,7 @@ class Kernels:
     # stream.  Off: the HBM-bound column sum overlaps the MFMA-bound GEMMs for free, while the fused reduction
     # lengthens the dgrad chain (measured -2.5 % step rate when fused).
     FUSE_COLSUM = os.environ.get("PM_FUSE_COLSUM", "0") == "1"
-    gemm_variant = 0  # pm_gemm_opts.variant: 0 = the dispatcher's heuristics (tuning scripts set it per Kernels object)
+    gemm_variant = int(os.environ.get("PM_GEMM_VARIANT", "0"))  # pm_gemm_opts.variant: 0 = the dispatcher's heuristics (tuning scripts set it per Kernels object)
 
     # -- scratch buffers: sized by the library's own queries (pm_gemm_workspace_bytes / pm_workspace_bytes), cached per
     #    shape; a buffer only ever grows, and growing it (first step of a new shape) drains the device first because the
