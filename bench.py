@@ -463,6 +463,11 @@ def run_workload(args, workload, batch, device, world, rank, headline):
     if not (loss_val == loss_val):
         sys.exit("non-finite loss in the timed region")
     rec = None
+    stats = None
+    if not args.no_kernel_stats:
+        # EVERY rank runs the instrumented steps (they contain the gradient all-reduces: a rank that skipped them would
+        # leave the others waiting in RCCL); only rank 0 reports
+        stats = kernel_stats(model, eager_step)
     if rank == 0:
         ips = batch * world * args.steps / dt
         per_gpu_tflops = ips / world * GFLOP_PER_IMG[workload] / 1e3
@@ -470,8 +475,8 @@ def run_workload(args, workload, batch, device, world, rank, headline):
         roof = {"bound": "mfma", "achieved": round(per_gpu_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(per_gpu_tflops / peak, 4), "traffic": None,
                 "basis": f"{GFLOP_PER_IMG[workload]} algorithmic GFLOP/img/step x img/s/GPU (BASELINE.md §3)"}
-        if not args.no_kernel_stats:
-            ks, hb, at, gt = kernel_stats(model, eager_step)
+        if stats is not None:
+            ks, hb, at, gt = stats
             dom = max(ks.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])
             roof["kernel"] = {"name": f"gemm_kernel<{args.precision},{dom[0]}>", **dom[1],
                               "frac": round(dom[1]["tflops"] / peak, 4),
