@@ -135,7 +135,7 @@ def kernel_stats(model, step):
     """Per-launch HIP-event timing of the GEMMs, LayerNorms and attention calls of one step (events recorded on the stream
     each kernel is launched on)."""
     k = model._rt.k
-    orig = dict(gemm=k.gemm, lnf=k.layernorm_fwd, lnb=k.layernorm_bwd, af=k.attention_fwd, ab=k.attention_bwd)
+    orig = dict(gemm=k.gemm, lnf=k.layernorm_fwd, lnb=k.layernorm_bwd, af=k.attention_fwd, ab=k.attention_bwd, wg=k.wgrad_group)
     rec, hbm, att = [], [], []
     act_b = 2 if k.precision == "bf16" else 4
 
@@ -146,6 +146,13 @@ def kernel_stats(model, step):
         e0, e1 = ev2()
         e0.record(); orig["gemm"](A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, **kw); e1.record()
         rec.append((("tn" if akm else "n") + ("n" if bkm else "t"), M, N, K, e0, e1))
+
+    def wgrad_group(items, K):
+        e0, e1 = ev2()
+        e0.record(); ok = orig["wg"](items, K); e1.record()
+        if ok:
+            rec.append(("wgrad_group", sum(it[2].shape[0] * it[2].shape[1] for it in items), 1, K, e0, e1))
+        return ok
 
     def ln_fwd(x, gamma, beta, y, mean, rstd, M, D):
         e0, e1 = ev2()
@@ -168,6 +175,7 @@ def kernel_stats(model, step):
         att.append(("attention_bwd", 10.0 * B * H * N * N * dh, e0, e1))
 
     k.gemm, k.layernorm_fwd, k.layernorm_bwd, k.attention_fwd, k.attention_bwd = gemm, ln_fwd, ln_bwd, attn_fwd, attn_bwd
+    k.wgrad_group = wgrad_group
     try:
         for _ in range(3):
             rec.clear(); hbm.clear(); att.clear()
@@ -175,7 +183,7 @@ def kernel_stats(model, step):
         torch.cuda.synchronize()
     finally:
         k.gemm, k.layernorm_fwd, k.layernorm_bwd = orig["gemm"], orig["lnf"], orig["lnb"]
-        k.attention_fwd, k.attention_bwd = orig["af"], orig["ab"]
+        k.attention_fwd, k.attention_bwd, k.wgrad_group = orig["af"], orig["ab"], orig["wg"]
 
     def fold(items, unit):
         d = {}
@@ -478,7 +486,9 @@ def run_workload(args, workload, batch, device, world, rank, headline):
         if stats is not None:
             ks, hb, at, gt = stats
             dom = max(ks.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])
-            roof["kernel"] = {"name": f"gemm_kernel<{args.precision},{dom[0]}>", **dom[1],
+            names = {"nt": "gemm_v3_kernel (forward: X [M,K] x W [N,K]^T)", "nn": "gemm_v3_kernel (dgrad: dY [M,K] x W [K,N])",
+                     "tnn": "gemm_v3_kernel (split-K weight gradient)", "wgrad_group": "wgrad_group_kernel (all dW of a block, full-K tiles)"}
+            roof["kernel"] = {"name": names.get(dom[0], dom[0]), "class": dom[0], **dom[1],
                               "frac": round(dom[1]["tflops"] / peak, 4),
                               "note": "in-step launch times: launches of the two forward chains / of the dgrad and "
                                       "weight-gradient streams overlap, so each shares the CUs (stand-alone rates: DESIGN.md)"}

@@ -151,6 +151,35 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
   const float half_erfc = 0.5f * p * t * e;  // 0.5 * erfc(|x|/sqrt2)
   cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
 }
+// The same on two values at once: the polynomial / product chain as packed f32 math (v_pk_fma_f32, v_pk_mul_f32: two
+// lanes' worth per issue slot), only rcp / exp2 / the sign select per component.  The GEMM epilogues that apply GELU or
+// its derivative to a 256x256 tile are VALU-bound there (~20 ops per element, no MFMA to hide behind): ~13 slots per
+// element instead of ~18.  Same operations in the same order per component as gelu_parts.
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& e) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 den = __builtin_elementwise_fma(ax, f32x2{0.2316418882f, 0.2316418882f}, f32x2{1.0f, 1.0f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  const f32x2 a = (x * -0.72134752044448170368f) * x;
+  e = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  f32x2 p = {1.061405429f, 1.061405429f};
+  p = __builtin_elementwise_fma(p, t, f32x2{-1.453152027f, -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
+  const f32x2 half_erfc = ((p * 0.5f) * t) * e;
+  const f32x2 upper = f32x2{1.0f, 1.0f} - half_erfc;
+  cdf = f32x2{x[0] >= 0.f ? upper[0] : half_erfc[0], x[1] >= 0.f ? upper[1] : half_erfc[1]};
+}
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  f32x2 cdf, e;
+  gelu_parts2(x, cdf, e);
+  return x * cdf;
+}
+__device__ __forceinline__ f32x2 gelu_erf_grad2(f32x2 x) {
+  f32x2 cdf, e;
+  gelu_parts2(x, cdf, e);
+  return __builtin_elementwise_fma(x * 0.39894228040143267794f, e, cdf);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
   float cdf, e;
   gelu_parts(x, cdf, e);
@@ -160,4 +189,26 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   float cdf, e;
   gelu_parts(x, cdf, e);
   return cdf + x * 0.39894228040143267794f * e;
+}
+
+// f32x4 forms used by the GEMM epilogues
+__device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
+#ifdef PM_GELU_SCALAR  // A/B build (scratch/build_alt.sh): one value at a time
+  return f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+#else
+  const f32x2 a = gelu_erf2(f32x2{v[0], v[1]}), b = gelu_erf2(f32x2{v[2], v[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+#endif
+}
+__device__ __forceinline__ f32x4 gelu_erf_grad4(f32x4 v) {
+#ifdef PM_GELU_SCALAR
+  return f32x4{gelu_erf_grad(v[0]), gelu_erf_grad(v[1]), gelu_erf_grad(v[2]), gelu_erf_grad(v[3])};
+#else
+  const f32x2 a = gelu_erf_grad2(f32x2{v[0], v[1]}), b = gelu_erf_grad2(f32x2{v[2], v[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+#endif
+}
+// the value the backward pass will see: the pre-activation after its round trip through the activation dtype
+template <typename T> __device__ __forceinline__ f32x4 round_through(f32x4 v) {
+  return f32x4{to_f32<T>(from_f32<T>(v[0])), to_f32<T>(from_f32<T>(v[1])), to_f32<T>(from_f32<T>(v[2])), to_f32<T>(from_f32<T>(v[3]))};
 }

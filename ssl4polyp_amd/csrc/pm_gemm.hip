@@ -221,12 +221,10 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int epi, long off, 
   } else {
     if (epi == PM_EPI_GELU) {
       store4<T>(reinterpret_cast<T*>(a.aux) + off, v);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = gelu_erf(to_f32<T>(from_f32<T>(v[e])));  // the value backward will see
+      v = gelu_erf4(round_through<T>(v));  // gelu of the value backward will see
     } else if (epi == PM_EPI_DGELU) {
       const f32x4 pre = load4<T>(reinterpret_cast<const T*>(a.aux) + off);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(pre[e]);
+      v *= gelu_erf_grad4(pre);
     }
     if (a.c_dtype == PM_F32)
       store4<float>(reinterpret_cast<float*>(a.C) + off, v);
@@ -257,15 +255,12 @@ __device__ __forceinline__ void epilogue_batch(const GemmArgs& a, int epi, const
 #pragma unroll
     for (int e = 0; e < NV; ++e) pre[e] = load4<__bf16>(reinterpret_cast<const __bf16*>(a.aux) + off[e]);
 #pragma unroll
-    for (int e = 0; e < NV; ++e)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[e][k] *= gelu_erf_grad(pre[e][k]);
+    for (int e = 0; e < NV; ++e) v[e] *= gelu_erf_grad4(pre[e]);
   } else if (epi == PM_EPI_GELU) {
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
       if (ok[e]) store4<__bf16>(reinterpret_cast<__bf16*>(a.aux) + off[e], v[e]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[e][k] = gelu_erf(to_f32<__bf16>(from_f32<__bf16>(v[e][k])));  // what backward will see
+      v[e] = gelu_erf4(round_through<__bf16>(v[e]));  // what backward will see
     }
   }
   if (a.c_dtype == PM_F32) {
@@ -288,21 +283,16 @@ __device__ __forceinline__ void epilogue_batch8(const GemmArgs& a, int epi, cons
 #pragma unroll
     for (int u = 0; u < NV; ++u) load8_bf16(reinterpret_cast<const __bf16*>(a.aux) + off[u], plo[u], phi[u]);
 #pragma unroll
-    for (int u = 0; u < NV; ++u)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        lo[u][k] *= gelu_erf_grad(plo[u][k]);
-        hi[u][k] *= gelu_erf_grad(phi[u][k]);
-      }
+    for (int u = 0; u < NV; ++u) {
+      lo[u] *= gelu_erf_grad4(plo[u]);
+      hi[u] *= gelu_erf_grad4(phi[u]);
+    }
   } else if (epi == PM_EPI_GELU) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       if (ok[u]) store8_bf16(reinterpret_cast<__bf16*>(a.aux) + off[u], lo[u], hi[u]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {  // gelu of the value backward will see (the bf16-rounded pre-activation)
-        lo[u][k] = gelu_erf(to_f32<__bf16>(from_f32<__bf16>(lo[u][k])));
-        hi[u][k] = gelu_erf(to_f32<__bf16>(from_f32<__bf16>(hi[u][k])));
-      }
+      lo[u] = gelu_erf4(round_through<__bf16>(lo[u]));  // gelu of the value backward will see (the bf16-rounded pre-activation)
+      hi[u] = gelu_erf4(round_through<__bf16>(hi[u]));
     }
   }
 #pragma unroll

@@ -151,6 +151,7 @@ class Kernels:
 
     GROUP_WGRAD = os.environ.get("PM_GROUP_WGRAD", "1") != "0"  # A/B switch: one grouped weight-gradient launch per block
     GROUP_BLOCKS = int(os.environ.get("PM_GROUP_BLOCKS", "0"))  # CUs the grouped launch may take (0 = one workgroup per tile)
+    GROUP_MIN_TILES = int(os.environ.get("PM_GROUP_MIN_TILES", "64"))
     GROUP_BIAS = os.environ.get("PM_GROUP_BIAS", "1") != "0"    # qkv / fc1 bias gradients inside that launch (no pm_colsum pass)
 
     def wgrad_group(self, items, K) -> bool:
@@ -170,8 +171,15 @@ class Kernels:
 
     def can_group_wgrad(self, K: int, dims) -> bool:
         """Same admission test as pm_wgrad_group (bf16, whole 32-token k-steps, long K, tiles of at least 256 x 128)."""
-        return (self.GROUP_WGRAD and self.precision == "bf16" and K % 32 == 0 and K >= 2048 and
-                all(o >= 256 and i >= 128 and o % 8 == 0 and i % 8 == 0 for o, i in dims))
+        if not (self.GROUP_WGRAD and self.precision == "bf16" and K % 32 == 0 and K >= 2048 and
+                all(o >= 256 and i >= 128 and o % 8 == 0 and i % 8 == 0 for o, i in dims)):
+            return False
+        # Enough 256x256 tiles to fill the weight-gradient stream's share of the chip with ONE full-K tile per CU (ViT-B
+        # block: 108).  The 512-wide MAE decoder block has 48: as 96 tiles of 256x128 the kernel is barrier-bound (12.7 %
+        # MFMA busy against 23.3 %, profiles/r2_b_mae_bs256_pmc_mfma_util.txt) and a launch outlasts the dgrad chain it
+        # runs beside, so those gradients keep the split-K path (PM_GROUP_MIN_TILES=0 forces grouping).
+        t256 = sum(((o + 255) // 256) * ((i + 255) // 256) for o, i in dims)
+        return t256 >= self.GROUP_MIN_TILES
 
     def linear_wgrad(self, dy, x, dW, M, N_out, K_in, accumulate):
         """dW[N_out,K_in] (+)= dy[M,N_out]^T @ x[M,K_in]  (both operands k-major, f32 output)."""

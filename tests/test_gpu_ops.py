@@ -612,6 +612,7 @@ def test_wgrad_group(K, dims):
         db = rnd(n_out, seed=430 + j) if j != 2 else None  # bias gradient (+=) beside the GEMM for all but one problem
         items.append((dy, x, dW, acc, db))
         want.append((dy.float().t() @ x.float() + (base if acc else 0), None if db is None else db + dy.float().sum(0)))
+    k.GROUP_MIN_TILES = 0  # (the engine groups only stacks with >= 64 tiles of 256x256; here every tile shape is exercised)
     assert k.can_group_wgrad(K, dims)
     assert k.wgrad_group(items, K)
     tol = 3e-5 * math.sqrt(K / 32)
