@@ -34,7 +34,9 @@ sys.path.insert(0, REPO)
 GFLOP_PER_IMG = {"cls": 105.38, "mae": 58.16}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense bf16 MFMA / f32 MFMA
 PEAK_HBM_GBPS = 8000.0                         # MI355X_MICROARCH.md: HBM3E
-OVERLAP_ADAMW = os.environ.get("PM_OVERLAP_ADAMW", "1") != "0"  # A/B switch: AdamW beside the next forward
+# AdamW on the side stream beside the next forward: +0.5..1 % on the fine-tune step (its forward is MFMA-bound), -1.3 % on the
+# MAE step (its encoder forward on 50 tokens is short and HBM-hungry itself); PM_OVERLAP_ADAMW=0/1 forces either
+OVERLAP_ADAMW = {"cls": os.environ.get("PM_OVERLAP_ADAMW", "1") != "0", "mae": os.environ.get("PM_OVERLAP_ADAMW", "0") != "0"}
 WORKLOAD_NAME = {"cls": "ViT-B/16 classification fine-tune", "mae": "MAE pre-train ViT-B/16 mask 0.75"}
 
 
@@ -81,11 +83,11 @@ def build(workload, precision, device, world, batch):
         hid = {id(p) for p in head}
         groups = [{"params": head, "name": "head"},
                   {"params": [p for p in model.parameters() if id(p) not in hid and p.requires_grad], "name": "backbone"}]
-        opt = FusedAdamW(model, groups, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.05, overlap_forward=OVERLAP_ADAMW)
+        opt = FusedAdamW(model, groups, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.05, overlap_forward=OVERLAP_ADAMW["cls"])
     else:
         # main_pretrain.py:201-218: lr = blr * eff_batch / 256, betas (0.9, 0.95), no decay on 1-D params
         lr = 1e-3 * batch * world / 256
-        opt = FusedAdamW(model, add_weight_decay(model, 0.05), lr=lr, betas=(0.9, 0.95), overlap_forward=OVERLAP_ADAMW)
+        opt = FusedAdamW(model, add_weight_decay(model, 0.05), lr=lr, betas=(0.9, 0.95), overlap_forward=OVERLAP_ADAMW["mae"])
     opt.grad_sync = ddp.sync
     opt.grad_scale = 1.0 / world
     return model, ddp, opt
@@ -257,6 +259,7 @@ def cpu_baseline(workload, full):
         for _ in range(timed):
             one()
         dt = time.perf_counter() - t0
+        print(f"[bench] cpu baseline: bs={B} threads={threads}: {B * timed / dt:.2f} img/s", file=sys.stderr, flush=True)
         return {"batch": B, "threads": threads, "warmup": warm, "timed_steps": timed, "images_per_sec": round(B * timed / dt, 3)}
 
     prev = torch.get_num_threads()
