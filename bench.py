@@ -318,6 +318,14 @@ def parity_block(workload, model, imgs, labels, precision):
             mats = {n: e for n, e in errs.items() if leaves[n].ndim >= 2 and leaves[n].shape[0] > 1}
             vecs = {n: e for n, e in errs.items() if n not in mats}
             wm, wv = max(mats, key=mats.get), max(vecs, key=vecs.get)
+            if precision == "bf16":
+                # what bf16 OPERANDS alone cost on this very configuration: the oracle with the same tensors rounded to bf16
+                # at the same points, on the CPU, no kernel involved (oracle/vit_bf16_sim.py).  Fresh-init weights and
+                # N(0,1) images are a harsher case than the tests' generated weights (2.2e-2 against 6.8e-3).
+                from oracle import vit_bf16_sim as S
+                with torch.no_grad():
+                    sim = S.vit_classify(sd, imgs.cpu(), cfg)
+                out.update(bf16_emulation_logits_max_rel=rel(sim, lr.detach()), logits_vs_bf16_emulation_max_rel=rel(logits.detach(), sim))
             out.update(logits_max_rel=rel(logits.detach(), lr.detach()), loss_rel=rel(loss.detach(), lo.detach()),
                        weight_grad_rel_l2_worst=mats[wm], weight_grad_rel_l2_worst_name=wm,
                        weight_grad_rel_l2_median=sorted(mats.values())[len(mats) // 2],
