@@ -164,6 +164,41 @@ def test_vitb_classifier_vs_oracle_at_bench_dispatch(B, prec):
     _grad_report(vm.named_parameters(), grads, tol_m, f"cls B={B} {prec}", tol_v)
 
 
+@pytest.mark.parametrize("mode", ["none", "head+1", "head+2"])
+def test_vitb_finetune_freeze_modes_vs_oracle(mode):
+    """C5's fine-tune regimes at ViT-B/16 size (finetune.py:49-91: "none" = linear probe, "head+k" = lin_head + the last k
+    blocks; frozen parameters get no gradient): the trainable parameters' gradients must equal the oracle's full-model
+    gradients for those parameters (freezing does not change the mathematics), the frozen ones stay None, and linear probe
+    must run without the 12-block training workspace."""
+    import ssl4polyp_amd as A
+    B = 16
+    sd, imgs, labels, logits_ref, loss_ref, grads = _oracle_cls(B)
+    vm = A.get_MAE_backbone(None, True, 2, False, None, precision="fp32")
+    sd_mae = dict(sd)
+    sd_mae["decoder_pos_embed"] = vm.state_dict()["decoder_pos_embed"]
+    vm.load_state_dict(sd_mae)
+    vm.to(DEV)
+    tail = {"none": 0, "head+1": 1, "head+2": 2}[mode]
+    keep = tuple(f"blocks.{11 - j}." for j in range(tail)) + ("lin_head.",)
+    for n, p in vm.named_parameters():  # what configure_finetune_parameters(model, mode) does
+        p.requires_grad_(n.startswith(keep))
+    vm.frozen = mode == "none"
+    logits = vm(imgs.to(DEV))
+    A.supervised_loss(logits, labels.to(DEV), pos_weight=1.7).backward()
+    assert rel(logits, logits_ref) < 1e-3
+    n_train = 0
+    for n, p in vm.named_parameters():
+        if n.startswith(keep):
+            assert rel_l2(p.grad, grads[n]) < 1e-3 or n.endswith("attn.qkv.bias"), n
+            n_train += 1
+        else:
+            assert p.grad is None, n
+    assert n_train == 2 + 12 * tail
+    if mode == "none":  # forward-only workspace: two block workspaces were pooled, not twelve
+        pools = vm._rt.pool
+        assert all(len(ws.blocks) <= 2 for lst in pools.values() for ws in lst), {k: [len(w.blocks) for w in v] for k, v in pools.items()}
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_vitb_mae_vs_oracle_at_bench_dispatch(prec):
     """B = 48: encoder M = 2400, decoder M = 9456 -> ring kernels for forward, dgrad and split-K wgrad of both stacks."""
