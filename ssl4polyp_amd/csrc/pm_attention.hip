@@ -73,7 +73,7 @@ __device__ __forceinline__ Frag16 frag_global(const T* __restrict__ rowptr, bool
 // acc_out[d][lane] += sum over the 32 rows r of X:  Img[rb + r][d0 + d] * X[r][lane]
 // where X is a 32x32 accumulator tile (rows in registers, column on the lane) used as the B operand.
 template <typename T, int DH>
-__device__ __forceinline__ f32x16 mma_imgT_acc(const char* img, int rb, int d0, const f32x16& x, f32x16 acc, int lane) {
+__device__ __forceinline__ f32x16 mma_imgT_acc(const char* PM_LDS_IMAGE img, int rb, int d0, const f32x16& x, f32x16 acc, int lane) {
   constexpr int RB = DH * sizeof(T);
   if constexpr (sizeof(T) == 2) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, hh = g >> 1;

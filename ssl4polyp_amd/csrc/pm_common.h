@@ -4,6 +4,19 @@
 #include <stdint.h>
 #include "../../include/polypmae.h"
 
+// Qualifier of the LDS image pointer in the functions that read MFMA fragments with ds_read_b64_tr_b16.
+// The waitcnt pass of the compiler guards every LDS read whose memory operand carries no alias scope with
+// `s_waitcnt vmcnt(0)` while LDS-DMA loads (global_load_lds) are in flight -- in a ring that keeps the next stages in
+// flight BEHIND the reads of the current one (counted vmcnt + barrier, placed by hand) that wait serialises the
+// prefetch: the stage issued in k-step t had to land by the top of k-step t+1.  `__restrict__` on the image pointer
+// gives the transpose reads an alias scope (as the plain ds_read_b128 fragment reads already have), and the pass
+// leaves them alone.  -DPM_AUTO_VMCNT restores the guarded form (A/B builds).
+#ifdef PM_AUTO_VMCNT
+#define PM_LDS_IMAGE
+#else
+#define PM_LDS_IMAGE __restrict__
+#endif
+
 #define PM_WAVE 64
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -159,7 +159,7 @@ __device__ __forceinline__ void stage_glds(char* tile, const T* __restrict__ bas
 
 // ---- LDS -> MFMA operand fragment -----------------------------------------------------------
 template <typename T, bool KMAJOR>
-__device__ __forceinline__ Frag16 read_frag(const char* tile, int rb, int kk, int lane) {
+__device__ __forceinline__ Frag16 read_frag(const char* PM_LDS_IMAGE tile, int rb, int kk, int lane) {
   Frag16 f;
   if constexpr (!KMAJOR) {
     const int row = rb + (lane & 31);
@@ -539,7 +539,7 @@ __device__ __forceinline__ Frag16 v3_frag_kn(const char* tile, int rb, int kk, i
 }
 
 template <int RB>
-__device__ __forceinline__ Frag16 v3_frag_km(const char* tile, int rb, int kk, int lane) {
+__device__ __forceinline__ Frag16 v3_frag_km(const char* PM_LDS_IMAGE tile, int rb, int kk, int lane) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
   const int ch = (rb >> 3) + 2 * (g & 1) + (p >> 1);
   const int sw = 16 * (ch ^ (q << 2)) + 8 * (p & 1);

@@ -153,6 +153,10 @@ class Kernels:
     GROUP_BLOCKS = int(os.environ.get("PM_GROUP_BLOCKS", "0"))  # CUs the grouped launch may take (0 = one workgroup per tile)
     GROUP_MIN_TILES = int(os.environ.get("PM_GROUP_MIN_TILES", "64"))
     GROUP_BIAS = os.environ.get("PM_GROUP_BIAS", "1") != "0"    # qkv / fc1 bias gradients inside that launch (no pm_colsum pass)
+    # The last blocks of a backward pass (lowest trainable ones) have no dgrad chain below them to run beside: a grouped
+    # launch there holds 108 CUs for ~0.4 ms while the rest idle, so those blocks issue their four gradients one by one
+    # (whole-chip split-K launches, each as soon as its dY exists).
+    UNGROUP_TAIL = int(os.environ.get("PM_UNGROUP_TAIL", "1"))
 
     def wgrad_group(self, items, K) -> bool:
         """items: [(dy [K, n_out], x [K, n_in], dW f32 [n_out, n_in], accumulate[, dbias f32 [n_out] (+=)])].  One launch for all
@@ -384,7 +388,7 @@ class BlockStack:
 
             # One grouped launch for the block's four weight gradients (full-K tiles, no split-K slabs), issued once the
             # whole dgrad chain of the block is enqueued; it runs beside block i-1's chain.
-            grouped = tr and k.can_group_wgrad(M, ((D, Hd), (Hd, D), (D, D), (3 * D, D)))
+            grouped = tr and i - lowest >= k.UNGROUP_TAIL and k.can_group_wgrad(M, ((D, Hd), (Hd, D), (D, D), (3 * D, D)))
             # ---- MLP branch ----
             if tr and not grouped:
                 fork()
