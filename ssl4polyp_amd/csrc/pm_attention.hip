@@ -486,7 +486,8 @@ template <int DH>
 int launch_fwd2(const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t s) {
   constexpr int NT = 7;
   const int BH = B * H;
-  const int rounds = (BH + 255) / 256;          // heads per workgroup on a 256-CU chip ...
+  constexpr int SLOTS = DH == 32 ? 512 : 256;   // workgroups the chip holds at once (72 KiB of LDS at dh = 32: two per CU)
+  const int rounds = (BH + SLOTS - 1) / SLOTS;  // heads per workgroup ...
   const int grid = (BH + rounds - 1) / rounds;  // ... spread evenly: no workgroup walks one head more than another
   constexpr size_t lds = 5 * NT * 32 * DH * 2;
   const float scale = 1.0f / sqrtf((float)DH);
@@ -725,6 +726,7 @@ int dispatch_bwd(int nt, const void* qkv, const void* out, const void* dout, con
 
 // A/B switch for the tuning scripts (PM_ATTN_V1=1: the one-block-per-head kernels everywhere); read once.
 const bool g_attn_v1 = [] { const char* e = getenv("PM_ATTN_V1"); return e && e[0] == '1'; }();
+const bool g_attn_fwd2_dh32 = [] { const char* e = getenv("PM_ATTN_FWD2_DH32"); return e && e[0] == '1'; }();
 
 inline int check_shape(int B, int N, int H, int dh, int dtype) {
   if (B <= 0 || N <= 0 || H <= 0) return PM_ESHAPE;
@@ -747,6 +749,7 @@ extern "C" int pm_attention_fwd(const void* qkv, void* out, float* lse, int B, i
     // persistent double-buffered form for the ViT-B encoder heads (dh = 64, N = 197: 26 vs 28 us); the 32-wide MAE decoder
     // heads are faster one block per head, two blocks per CU (70 vs 77 us) -- both are bound by the strided qkv reads
     if (nt == 7 && dh == 64 && !g_attn_v1) return launch_fwd2<64>(qkv, out, lse, B, N, H, s);
+    if (nt == 7 && dh == 32 && g_attn_fwd2_dh32) return launch_fwd2<32>(qkv, out, lse, B, N, H, s);
     return dh == 64 ? dispatch_fwd<__bf16, 64>(nt, qkv, out, lse, B, N, H, s)
                     : dispatch_fwd<__bf16, 32>(nt, qkv, out, lse, B, N, H, s);
   }

@@ -627,7 +627,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
   // operand that is all ones in row 0 for k-groups {0,2} and in row 1 for k-groups {1,3} (lanes 0, 32 / 17, 49) therefore
   // yields D[0][c] = sum_k X[c][k], D[1][c] = sum_k X[16+c][k]: lane c < 16 holds them in registers 0 and 1.
   // 2*MT extra 16-cycle MFMAs per k-step, only in the waves of column 0 of the tiles of column 0 (each row once).
-  static_assert(!XSUM || (XK && !SWP), "row sums ride on the k-major X fragments of the ping-pong / plain loops");
+  static_assert(!XSUM || XK, "row sums ride on the k-major X fragments");
   f32x4 xs[MT];
   Frag16 ones_sel;
   bool do_xsum = false;
@@ -765,6 +765,15 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
 #ifdef PM_GEMM_STAMP
         if (m == NMF / 2 - 1) PM_STAMP(3);
 #endif
+      }
+      if constexpr (XSUM) {
+        if (do_xsum) {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+              xs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_sel.h, cx[kk][j].h, xs[j], 0, 0, 0);
+        }
       }
 #ifdef PM_GEMM_STAMP
       PM_STAMP(4);
@@ -1130,6 +1139,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroupArgs g) {
 #ifdef PM_GEMM_STAMP
     a.stamps = nullptr;
 #endif
+    // (the software-pipelined loop needs 254 VGPRs without the row sums: with them it spills 73 and runs 1.5x slower;
+    //  without them, bias gradients by separate column-sum passes, it equals this loop with the row sums inside)
     gemm_v3_tile<BM_, BN_, WM, WN, true, 4, true, true, true, 8, false, true>(a, tile - pr.tile_begin, 0);
     __syncthreads();  // every wave is done with the LDS ring before the next tile's first stages are issued
   }
@@ -1282,6 +1293,8 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
 
 namespace {
 
+const bool g_dgrad_pp = [] { const char* e = getenv("PM_DGRAD_PP"); return e && e[0] == '1'; }();  // A/B: dgrads on the ping-pong loop
+
 int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
                   const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid, int M, int N,
                   int K, void* workspace, size_t ws_bytes, const pm_gemm_opts* opts, void* stream) {
@@ -1339,8 +1352,10 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
         const long nt = (N + 255) / 256;
         const long c256 = (((M + 255) / 256 * nt + 255) / 256) * 256, c192 = (((M + 191) / 192 * nt + 255) / 256) * 192;
         if (c192 < c256) cfg = 10;
-        // f32 residual outputs of the forward (k-normal W): the software-pipelined loop wins (fc2 80 -> 70 us)
-        if (epilogue == PM_EPI_RESIDUAL && !b_kmajor) cfg = cfg == 10 ? 26 : 25;
+        // f32 residual outputs of the forward (k-normal W): the software-pipelined loop wins (fc2 80 -> 70 us);
+        // so it does for every dgrad (W read as stored by ds_read_b64_tr_b16) since those reads stopped waiting for the
+        // whole DMA ring (PM_LDS_IMAGE): dfc1 66 -> 61 us, dqkv 51 -> 47, dfc2 101 -> 96, decoder dfc1 118 -> 107
+        if ((epilogue == PM_EPI_RESIDUAL && !b_kmajor) || (b_kmajor && !g_dgrad_pp)) cfg = cfg == 10 ? 26 : 25;
       }
     }
     switch (cfg) {
