@@ -112,8 +112,14 @@ typedef struct pm_wgrad_item {
   float* dbias;   /* optional f32 [n_out]: += column sums of dY = the Linear's bias gradient, computed beside the GEMM on
                      the matrix cores (the dY fragments are already in registers) instead of by a separate pm_colsum pass */
 } pm_wgrad_item;
-/* max_blocks: workgroups (= CUs) the launch may occupy; 0 = one per tile.  Fewer workgroups walk several tiles each. */
-int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_dtype, int max_blocks, void* stream);
+/* max_blocks: workgroups (= CUs) the launch may occupy; 0 = one per work item.  Fewer workgroups walk several items each.
+ * A group with fewer than 64 tiles of 256x256 and a long K (the 512-wide MAE decoder block: 48 tiles, K = 50 432 tokens)
+ * is cut into k-slices so that tiles x slices fills the chip (48 x 4): f32 partials go to `workspace`
+ * (pm_wgrad_group_workspace_bytes; 16-byte aligned) and ONE reduce launch on the same stream finishes every dW / dbias of
+ * the group in a fixed order.  With workspace == NULL (or too small) such a group runs whole-K tiles of 256x128 instead. */
+int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_dtype, int max_blocks, void* workspace, size_t ws_bytes,
+                   void* stream);
+size_t pm_wgrad_group_workspace_bytes(const pm_wgrad_item* items, int n, int K, int in_dtype);
 
 /* pm_gemm followed by the column sums of the stored result: colsum[n] += sum_m C[m][n] (f32 [N]) -- the bias gradient of
  * the Linear whose output gradient C is (reference: autograd of nn.Linear).  Convenience composition (pm_gemm_ws +

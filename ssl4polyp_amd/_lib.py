@@ -24,7 +24,7 @@ SIGNATURES = {
     "pm_gemm": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P],
     "pm_gemm_ws": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P],
     "pm_gemm_ex": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P, P],
-    "pm_wgrad_group": [P, I, I, I, I, P],
+    "pm_wgrad_group": [P, I, I, I, I, P, ctypes.c_size_t, P],
     "pm_gemm_colsum": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, P, I, I, I, P, ctypes.c_size_t, P],
     "pm_attention_fwd": [P, P, P, I, I, I, I, I, P],
     "pm_attention_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
@@ -53,7 +53,7 @@ SIGNATURES = {
     "pm_grad_stats": [P, L, P, P],
 }
 
-ABI_VERSION = 3  # pm_abi_version() of the library these signatures describe
+ABI_VERSION = 4  # pm_abi_version() of the library these signatures describe
 
 WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4
 
@@ -98,6 +98,8 @@ def load():
     lib.pm_gemm_workspace_bytes.argtypes = [I, I, I, I, I, I, P]
     lib.pm_workspace_bytes.restype = ctypes.c_size_t
     lib.pm_workspace_bytes.argtypes = [I, I, I]
+    lib.pm_wgrad_group_workspace_bytes.restype = ctypes.c_size_t
+    lib.pm_wgrad_group_workspace_bytes.argtypes = [P, I, I, I]
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
         fn.restype = c_int

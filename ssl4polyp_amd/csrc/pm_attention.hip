@@ -725,8 +725,14 @@ int dispatch_bwd(int nt, const void* qkv, const void* out, const void* dout, con
 }
 
 // A/B switch for the tuning scripts (PM_ATTN_V1=1: the one-block-per-head kernels everywhere); read once.
-const bool g_attn_v1 = [] { const char* e = getenv("PM_ATTN_V1"); return e && e[0] == '1'; }();
-const bool g_attn_fwd2_dh32 = [] { const char* e = getenv("PM_ATTN_FWD2_DH32"); return e && e[0] == '1'; }();
+bool attn_v1() {
+  static const bool v = [] { const char* e = getenv("PM_ATTN_V1"); return e && e[0] == '1'; }();
+  return v;
+}
+bool attn_fwd2_dh32() {  // the persistent forward for the 32-wide MAE decoder heads too (measured slower: 80 vs 71 us)
+  static const bool v = [] { const char* e = getenv("PM_ATTN_FWD2_DH32"); return e && e[0] == '1'; }();
+  return v;
+}
 
 inline int check_shape(int B, int N, int H, int dh, int dtype) {
   if (B <= 0 || N <= 0 || H <= 0) return PM_ESHAPE;
@@ -748,8 +754,8 @@ extern "C" int pm_attention_fwd(const void* qkv, void* out, float* lse, int B, i
   if (dtype == PM_BF16) {
     // persistent double-buffered form for the ViT-B encoder heads (dh = 64, N = 197: 26 vs 28 us); the 32-wide MAE decoder
     // heads are faster one block per head, two blocks per CU (70 vs 77 us) -- both are bound by the strided qkv reads
-    if (nt == 7 && dh == 64 && !g_attn_v1) return launch_fwd2<64>(qkv, out, lse, B, N, H, s);
-    if (nt == 7 && dh == 32 && g_attn_fwd2_dh32) return launch_fwd2<32>(qkv, out, lse, B, N, H, s);
+    if (nt == 7 && dh == 64 && !attn_v1()) return launch_fwd2<64>(qkv, out, lse, B, N, H, s);
+    if (nt == 7 && dh == 32 && attn_fwd2_dh32()) return launch_fwd2<32>(qkv, out, lse, B, N, H, s);
     return dh == 64 ? dispatch_fwd<__bf16, 64>(nt, qkv, out, lse, B, N, H, s)
                     : dispatch_fwd<__bf16, 32>(nt, qkv, out, lse, B, N, H, s);
   }
@@ -765,7 +771,7 @@ extern "C" int pm_attention_bwd(const void* qkv, const void* out, const void* do
   const int nt = (N + 31) / 32;
   hipStream_t s = pm_stream(stream);
   if (dtype == PM_BF16) {
-    if (!g_attn_v1)
+    if (!attn_v1())
       return dh == 64 ? dispatch_bwd_fused<64>(nt, qkv, out, dout, lse, dqkv, B, N, H, s)
                       : dispatch_bwd_fused<32>(nt, qkv, out, dout, lse, dqkv, B, N, H, s);
     return dh == 64 ? dispatch_bwd<__bf16, 64>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s)

@@ -59,6 +59,7 @@ struct GemmArgs {
   int split_k;       // >1: blockIdx.y = split, C = f32 slabs [split][M][ldc]
   int ksteps_split;  // k-steps per split
   float* xsum;         // grouped wgrad: xsum[m] += sum_k X(m, k) (= the bias gradient: column sums of dY), or NULL
+  int xsum_store;      // xsum[m] = ... instead of += (partial row sums of a k-slice, reduced later)
 #ifdef PM_GEMM_STAMP
   unsigned long long* stamps;  // diagnostic build only: per-wave cycle sums of the k-loop segments
 #endif
@@ -902,8 +903,8 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int m = m0 + wm * TM + 32 * j + lane;
-        if (m < a.M) a.xsum[m] += xs[j][0];
-        if (m + 16 < a.M) a.xsum[m + 16] += xs[j][1];
+        if (m < a.M) a.xsum[m] = (a.xsum_store ? 0.f : a.xsum[m]) + xs[j][0];
+        if (m + 16 < a.M) a.xsum[m + 16] = (a.xsum_store ? 0.f : a.xsum[m + 16]) + xs[j][1];
       }
     }
   }
@@ -1113,19 +1114,28 @@ struct WgradProb {
   int tile_begin;     // first global tile id of this problem
   int accumulate;     // dW += instead of dW =
   float* dbias;       // [M] += column sums of dY (the Linear's bias gradient), or NULL
+  float* slab;        // split > 1: f32 partial products [split][M][N] (caller's workspace)
+  float* bias_part;   // split > 1 and dbias: partial row sums [split][M]
+  long vec_begin;     // split > 1: first float4 index of this problem in the reduce launch
 };
 struct WgradGroupArgs {
   WgradProb p[kMaxGroup];
   int n, K, total_tiles;
+  int split;          // k-slices per tile (1: the tile's workgroup writes dW itself)
+  int ksteps_split;
+  long total_vec, bias_begin, bias_total;  // reduce launch: float4 items, then bias rows
 };
 
 template <int BM_, int BN_, int WM, int WN>
 __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroupArgs g) {
-  // gridDim.x workgroups (a multiple of 8, or total_tiles) walk the tiles t = blockIdx.x, + gridDim.x, ...: the caller
-  // chooses how many CUs the weight-gradient stream takes from the dgrad chain beside it.  xcd_remap gives every XCD a
-  // contiguous run of tile ids (same dY panel -> same private L2); with gridDim.x % 8 == 0 a workgroup stays on its XCD's run.
-  for (int t = blockIdx.x; t < g.total_tiles; t += gridDim.x) {
-    const int tile = xcd_remap(t, g.total_tiles);
+  // gridDim.x workgroups (a multiple of 8, or the whole work list) walk the (k-slice, tile) items t = blockIdx.x,
+  // + gridDim.x, ...: the caller chooses how many CUs the weight-gradient stream takes from the dgrad chain beside it.
+  // xcd_remap gives every XCD a contiguous run of items; within a k-slice consecutive items are neighbouring tiles
+  // (same dY panel -> same private L2); with gridDim.x % 8 == 0 a workgroup stays on its XCD's run.
+  const int work = g.total_tiles * g.split;
+  for (int t = blockIdx.x; t < work; t += gridDim.x) {
+    const int w = xcd_remap(t, work);
+    const int slice = w / g.total_tiles, tile = w - slice * g.total_tiles;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < kMaxGroup; ++i)
@@ -1135,14 +1145,53 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroupArgs g) {
     a.X = pr.dY; a.W = pr.X; a.ldx = pr.lddy; a.ldw = pr.ldx; a.bias = nullptr; a.C = pr.dW; a.ldc = pr.lddw; a.aux = nullptr;
     a.resid = nullptr; a.M = pr.M; a.N = pr.N; a.K = g.K; a.epilogue = pr.accumulate ? PM_EPI_ACCUM : PM_EPI_STORE;
     a.c_dtype = PM_F32; a.tiles_m = 0; a.tiles_n = pr.tiles_n; a.split_k = 1; a.ksteps_split = 0;
-    a.xsum = pr.dbias;
+    a.xsum = pr.dbias; a.xsum_store = 0;
+    if (g.split > 1) {  // a k-slice: plain f32 partials into the slab (gemm_v3_tile offsets C by the slice), reduced afterwards
+      a.C = pr.slab; a.ldc = pr.N; a.epilogue = PM_EPI_STORE; a.split_k = g.split; a.ksteps_split = g.ksteps_split;
+      a.xsum = pr.dbias ? pr.bias_part + (long)slice * pr.M : nullptr; a.xsum_store = 1;
+    }
 #ifdef PM_GEMM_STAMP
     a.stamps = nullptr;
 #endif
     // (the software-pipelined loop needs 254 VGPRs without the row sums: with them it spills 73 and runs 1.5x slower;
     //  without them, bias gradients by separate column-sum passes, it equals this loop with the row sums inside)
-    gemm_v3_tile<BM_, BN_, WM, WN, true, 4, true, true, true, 8, false, true>(a, tile - pr.tile_begin, 0);
+    gemm_v3_tile<BM_, BN_, WM, WN, true, 4, true, true, true, 8, false, true>(a, tile - pr.tile_begin, slice);
     __syncthreads();  // every wave is done with the LDS ring before the next tile's first stages are issued
+  }
+}
+
+// dW (+)= sum over the k-slices of the slab, dbias += sum of the partial row sums: fixed order, one launch for the group.
+__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgradGroupArgs g) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < g.bias_begin + g.bias_total; v += stride) {
+    if (v < g.total_vec) {
+      int pi = 0;
+#pragma unroll
+      for (int i = 1; i < kMaxGroup; ++i)
+        if (i < g.n && v >= g.p[i].vec_begin) pi = i;
+      const WgradProb& pr = g.p[pi];
+      const long e = (v - pr.vec_begin) * 4;  // element index in [M][N] (N % 8 == 0)
+      const long per = (long)pr.M * pr.N;
+      f32x4 acc = *reinterpret_cast<const f32x4*>(pr.slab + e);
+      for (int sl = 1; sl < g.split; ++sl) acc += *reinterpret_cast<const f32x4*>(pr.slab + sl * per + e);
+      const long m = e / pr.N, c = e - m * pr.N;
+      float* out = pr.dW + m * pr.lddw + c;
+      if (pr.accumulate) acc += *reinterpret_cast<const f32x4*>(out);
+      *reinterpret_cast<f32x4*>(out) = acc;
+    } else if (v >= g.bias_begin) {
+      long r = v - g.bias_begin;
+      for (int i = 0; i < g.n; ++i) {
+        const WgradProb& pr = g.p[i];
+        if (!pr.dbias) continue;
+        if (r < pr.M) {
+          float sum = 0.f;
+          for (int sl = 0; sl < g.split; ++sl) sum += pr.bias_part[(long)sl * pr.M + r];
+          pr.dbias[r] += sum;
+          break;
+        }
+        r -= pr.M;
+      }
+    }
   }
 }
 
@@ -1293,7 +1342,10 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
 
 namespace {
 
-const bool g_dgrad_pp = [] { const char* e = getenv("PM_DGRAD_PP"); return e && e[0] == '1'; }();  // A/B: dgrads on the ping-pong loop
+bool dgrad_pp() {  // A/B switch, read once: dgrads on the ping-pong loop
+  static const bool v = [] { const char* e = getenv("PM_DGRAD_PP"); return e && e[0] == '1'; }();
+  return v;
+}
 
 int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
                   const float* bias, void* C, long ldc, int c_dtype, int epilogue, void* aux, const float* resid, int M, int N,
@@ -1328,6 +1380,7 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
   a.tiles_n = (N + BN - 1) / BN;
   a.split_k = 1;
   a.xsum = nullptr;
+  a.xsum_store = 0;
 #ifdef PM_GEMM_STAMP
   a.stamps = g_stamps;
 #endif
@@ -1355,7 +1408,7 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
         // f32 residual outputs of the forward (k-normal W): the software-pipelined loop wins (fc2 80 -> 70 us);
         // so it does for every dgrad (W read as stored by ds_read_b64_tr_b16) since those reads stopped waiting for the
         // whole DMA ring (PM_LDS_IMAGE): dfc1 66 -> 61 us, dqkv 51 -> 47, dfc2 101 -> 96, decoder dfc1 118 -> 107
-        if ((epilogue == PM_EPI_RESIDUAL && !b_kmajor) || (b_kmajor && !g_dgrad_pp)) cfg = cfg == 10 ? 26 : 25;
+        if ((epilogue == PM_EPI_RESIDUAL && !b_kmajor) || (b_kmajor && !dgrad_pp())) cfg = cfg == 10 ? 26 : 25;
       }
     }
     switch (cfg) {
@@ -1452,26 +1505,82 @@ extern "C" int pm_gemm(const void* A, long lda, int a_kmajor, const void* B, lon
                     nullptr, 0, stream);
 }
 
-extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_dtype, int max_blocks, void* stream) {
-  if (!items || n <= 0) return PM_EINVAL;
-  if (n > kMaxGroup || K <= 0) return PM_ESHAPE;
-  if (in_dtype != PM_BF16) return PM_ESHAPE;              // (f32 mode keeps the per-GEMM split-K path)
-  if ((K % V3_KE) != 0 || K < 2048) return PM_ESHAPE;     // ring kernel: whole 32-element k-steps, long reduction
+namespace {
+
+// tuning hook, read once: work items (tiles x k-slices) a group with few tiles is cut into (default 224 of the 256 CUs)
+int group_split_target() {
+  static const int v = [] { const char* e = getenv("PM_GROUP_SPLIT_TARGET"); return e && e[0] ? atoi(e) : 224; }();
+  return v;
+}
+
+struct GroupPlan {
+  int status;        // PM_OK or the refusal
+  int bn;            // tile width
+  int split;         // k-slices per tile
+  int ksteps_split;
+  size_t ws_bytes;   // slabs + partial row sums (0 when split == 1)
+};
+
+GroupPlan plan_group(const pm_wgrad_item* items, int n, int K, int in_dtype) {
+  GroupPlan pl{PM_OK, 256, 1, 0, 0};
+  if (!items || n <= 0) { pl.status = PM_EINVAL; return pl; }
+  if (n > kMaxGroup || K <= 0) { pl.status = PM_ESHAPE; return pl; }
+  if (in_dtype != PM_BF16) { pl.status = PM_ESHAPE; return pl; }           // (f32 mode keeps the per-GEMM split-K path)
+  if ((K % V3_KE) != 0 || K < 2048) { pl.status = PM_ESHAPE; return pl; }  // ring kernel: whole 32-element k-steps, long reduction
   long t256 = 0;
   for (int i = 0; i < n; ++i) {
     const pm_wgrad_item& it = items[i];
-    if (!it.dY || !it.X || !it.dW) return PM_EINVAL;
-    if (it.n_out < 256 || it.n_in < 128) return PM_ESHAPE;
-    if ((it.n_out & 7) || (it.n_in & 7) || (it.lddy & 7) || (it.ldx & 7) || (it.lddw & 3)) return PM_EALIGN;
-    if (((uintptr_t)it.dY & 15) || ((uintptr_t)it.X & 15) || ((uintptr_t)it.dW & 15)) return PM_EALIGN;
+    if (!it.dY || !it.X || !it.dW) { pl.status = PM_EINVAL; return pl; }
+    if (it.n_out < 256 || it.n_in < 128) { pl.status = PM_ESHAPE; return pl; }
+    if ((it.n_out & 7) || (it.n_in & 7) || (it.lddy & 7) || (it.ldx & 7) || (it.lddw & 3)) { pl.status = PM_EALIGN; return pl; }
+    if (((uintptr_t)it.dY & 15) || ((uintptr_t)it.X & 15) || ((uintptr_t)it.dW & 15)) { pl.status = PM_EALIGN; return pl; }
     t256 += (long)((it.n_out + 255) / 256) * ((it.n_in + 255) / 256);
   }
-  // 256x256 tiles (twice the MFMAs per barrier, 128 FLOP per LDS-fill byte) when they still give >= 64 workgroups;
-  // otherwise 256x128 (the 512-wide MAE decoder: 48 -> 96 workgroups)
-  const int bn = t256 >= 64 ? 256 : 128;
+  // >= 64 tiles of 256x256 (a ViT-B block: 108): one full-K tile per workgroup, no slabs.  Fewer (the 512-wide MAE decoder
+  // block: 48 tiles, K = 50 432 tokens): each tile is cut into k-slices so that tiles x slices ~ the chip (48 x 4 = 192 work
+  // items of 394 k-steps), f32 partials in the caller's workspace, ONE reduce launch for the whole group.
+  const int nk = K / V3_KE;
+  if (t256 < 64) {
+    int split = (int)(group_split_target() / t256);
+    if (split > 8) split = 8;
+    if (split > nk / 128) split = nk / 128;  // >= 128 k-steps per slice: prologue / epilogue stay small
+    if (split > 1) {
+      pl.ksteps_split = (nk + split - 1) / split;
+      pl.split = (nk + pl.ksteps_split - 1) / pl.ksteps_split;  // no empty slice
+    }
+  }
+  if (pl.split > 1) {
+    for (int i = 0; i < n; ++i) {
+      pl.ws_bytes += (size_t)pl.split * items[i].n_out * items[i].n_in * sizeof(float);
+      if (items[i].dbias) pl.ws_bytes += (((size_t)pl.split * items[i].n_out * sizeof(float)) + 15) & ~(size_t)15;
+    }
+  } else {
+    pl.bn = t256 >= 64 ? 256 : 128;  // without slices: 256x128 tiles double the workgroups of a small group
+  }
+  return pl;
+}
+
+}  // namespace
+
+extern "C" size_t pm_wgrad_group_workspace_bytes(const pm_wgrad_item* items, int n, int K, int in_dtype) {
+  const GroupPlan pl = plan_group(items, n, K, in_dtype);
+  return pl.status == PM_OK ? pl.ws_bytes : 0;
+}
+
+extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_dtype, int max_blocks, void* workspace,
+                              size_t ws_bytes, void* stream) {
+  GroupPlan pl = plan_group(items, n, K, in_dtype);
+  if (pl.status != PM_OK) return pl.status;
+  if (pl.split > 1 && (!workspace || ws_bytes < pl.ws_bytes || ((uintptr_t)workspace & 15))) {
+    pl.split = 1;  // no room for the slabs: whole-K tiles, narrower so that there are twice as many
+    pl.bn = 128;
+  }
+  const int bn = pl.bn;
   WgradGroupArgs g;
-  g.n = n; g.K = K;
+  g.n = n; g.K = K; g.split = pl.split; g.ksteps_split = pl.ksteps_split;
   int total = 0;
+  long vec = 0;
+  char* ws = reinterpret_cast<char*>(workspace);
   for (int i = 0; i < n; ++i) {
     const pm_wgrad_item& it = items[i];
     WgradProb& p = g.p[i];
@@ -1480,14 +1589,29 @@ extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_d
     p.tiles_n = (it.n_in + bn - 1) / bn;
     p.tile_begin = total;
     total += ((it.n_out + 255) / 256) * p.tiles_n;
+    p.slab = nullptr; p.bias_part = nullptr; p.vec_begin = vec;
+    if (pl.split > 1) {
+      p.slab = reinterpret_cast<float*>(ws);
+      ws += (size_t)pl.split * it.n_out * it.n_in * sizeof(float);
+      if (it.dbias) {
+        p.bias_part = reinterpret_cast<float*>(ws);
+        ws += (((size_t)pl.split * it.n_out * sizeof(float)) + 15) & ~(size_t)15;
+      }
+      vec += (long)it.n_out * it.n_in / 4;
+    }
   }
   for (int i = n; i < kMaxGroup; ++i) g.p[i] = g.p[0];
   g.total_tiles = total;
-  int grid = total;
-  if (max_blocks > 0 && max_blocks < total) {
-    grid = (max_blocks / 8) * 8;  // whole XCD rounds: a workgroup keeps walking its own XCD's run of tiles
+  g.total_vec = vec; g.bias_begin = vec; g.bias_total = 0;
+  if (pl.split > 1)
+    for (int i = 0; i < n; ++i)
+      if (items[i].dbias) g.bias_total += items[i].n_out;
+  const int work = total * pl.split;
+  int grid = work;
+  if (max_blocks > 0 && max_blocks < work) {
+    grid = (max_blocks / 8) * 8;  // whole XCD rounds: a workgroup keeps walking its own XCD's run of items
     if (grid < 8) grid = 8;
-    if (grid > total) grid = total;
+    if (grid > work) grid = work;
   }
   hipStream_t s = pm_stream(stream);
   if (bn == 256) {
@@ -1501,5 +1625,11 @@ extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_d
     PM_ALLOW_LDS(kern, ring);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ring, s, g);
   }
+  int st = pm_check_launch();
+  if (st || pl.split == 1) return st;
+  const long items_r = g.bias_begin + g.bias_total;
+  int rgrid = (int)((items_r + 255) / 256);
+  if (rgrid > 2048) rgrid = 2048;
+  hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(rgrid), dim3(256), 0, s, g);
   return pm_check_launch();
 }

@@ -153,6 +153,7 @@ class Kernels:
     GROUP_BLOCKS = int(os.environ.get("PM_GROUP_BLOCKS", "0"))  # CUs the grouped launch may take (0 = one workgroup per tile)
     GROUP_MIN_TILES = int(os.environ.get("PM_GROUP_MIN_TILES", "64"))
     GROUP_BIAS = os.environ.get("PM_GROUP_BIAS", "1") != "0"    # qkv / fc1 bias gradients inside that launch (no pm_colsum pass)
+    GROUP_SPLIT = os.environ.get("PM_GROUP_SPLIT", "1") != "0"  # A/B switch: groups of < 64 tiles as k-sliced grouped launches
     # The last blocks of a backward pass (lowest trainable ones) have no dgrad chain below them to run beside: a grouped
     # launch there holds 108 CUs for ~0.4 ms while the rest idle, so those blocks issue their four gradients one by one
     # (whole-chip split-K launches, each as soon as its dY exists).
@@ -160,14 +161,20 @@ class Kernels:
 
     def wgrad_group(self, items, K) -> bool:
         """items: [(dy [K, n_out], x [K, n_in], dW f32 [n_out, n_in], accumulate[, dbias f32 [n_out] (+=)])].  One launch for all
-        (pm_wgrad_group); False when the shapes do not fit the grouped kernel (the caller then uses linear_wgrad)."""
+        (pm_wgrad_group; a group of few tiles and long K is cut into k-slices: slabs in a scratch buffer sized by
+        pm_wgrad_group_workspace_bytes, one reduce launch); False when the shapes do not fit the grouped kernel (the caller
+        then uses linear_wgrad)."""
         n = len(items)
         arr = (_lib.WgradItem * n)()
         for j, (dy, x, dW, acc, *rest) in enumerate(items):
             n_out, n_in = dW.shape
             arr[j] = _lib.WgradItem(_ptr(dy), n_out, _ptr(x), n_in, _ptr(dW), n_in, n_out, n_in, int(bool(acc)),
                                     _ptr(rest[0]) if rest and rest[0] is not None else None)
-        st = self.lib.pm_wgrad_group(arr, n, K, _lib.dtype_code(items[0][0].dtype), self.GROUP_BLOCKS, _stream())
+        dt = _lib.dtype_code(items[0][0].dtype)
+        key = ("group", K, dt, tuple((tuple(it[2].shape), len(it) > 4 and it[4] is not None) for it in items))
+        need = self._need(key, lambda: self.lib.pm_wgrad_group_workspace_bytes(arr, n, K, dt))
+        ws = self._scratch("_ws_group", need, items[0][0].device) if need else None
+        st = self.lib.pm_wgrad_group(arr, n, K, dt, self.GROUP_BLOCKS, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
         if st == _lib.PM_ESHAPE:
             return False
         _lib.check(st, "pm_wgrad_group")
@@ -178,12 +185,12 @@ class Kernels:
         if not (self.GROUP_WGRAD and self.precision == "bf16" and K % 32 == 0 and K >= 2048 and
                 all(o >= 256 and i >= 128 and o % 8 == 0 and i % 8 == 0 for o, i in dims)):
             return False
-        # Enough 256x256 tiles to fill the weight-gradient stream's share of the chip with ONE full-K tile per CU (ViT-B
-        # block: 108).  The 512-wide MAE decoder block has 48: as 96 tiles of 256x128 the kernel is barrier-bound (12.7 %
-        # MFMA busy against 23.3 %, profiles/r2_b_mae_bs256_pmc_mfma_util.txt) and a launch outlasts the dgrad chain it
-        # runs beside, so those gradients keep the split-K path (PM_GROUP_MIN_TILES=0 forces grouping).
+        # >= 64 tiles of 256x256 (ViT-B block: 108): one full-K tile per workgroup.  Fewer (the 512-wide MAE decoder block:
+        # 48) group as well when K is long enough to cut every tile into >= 2 k-slices of >= 128 k-steps (the library's
+        # plan: 48 tiles x 4 slices); otherwise the gradients keep the per-GEMM split-K path (PM_GROUP_MIN_TILES=0 forces
+        # grouping: whole-K tiles of 256x128).
         t256 = sum(((o + 255) // 256) * ((i + 255) // 256) for o, i in dims)
-        return t256 >= self.GROUP_MIN_TILES
+        return t256 >= self.GROUP_MIN_TILES or (self.GROUP_SPLIT and K // 32 >= 256)
 
     def linear_wgrad(self, dy, x, dW, M, N_out, K_in, accumulate):
         """dW[N_out,K_in] (+)= dy[M,N_out]^T @ x[M,K_in]  (both operands k-major, f32 output)."""
@@ -340,12 +347,14 @@ class BlockStack:
     def backward(self, ws: StackWorkspace, x_in: torch.Tensor, W, G, dx: torch.Tensor, dx_act: torch.Tensor,
                  last_bias_grad_done: bool, trainable: Sequence[bool], need_input_grad: bool,
                  accumulate: Callable[[str, int], bool], on_block_done: Optional[Callable[[int], None]] = None,
-                 prev_bias_grad: Optional[torch.Tensor] = None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+                 prev_bias_grad: Optional[torch.Tensor] = None,
+                 ends_pass: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
         """dx / dx_act: gradient w.r.t. the stack output (f32 + act copy).  G[i][name] = f32 gradient
         tensors (vectors are += targets and must be zeroed or hold the running sum; matrices follow
         accumulate(name, i)).  `last_bias_grad_done`: the producer of dx already added colsum(dx) into the
         last block's fc2.bias gradient.  `prev_bias_grad`: bias gradient of the Linear that produced the
-        stack input (receives colsum of the input gradient), if any.
+        stack input (receives colsum of the input gradient), if any.  `ends_pass`: nothing but a short tail follows this
+        stack in the backward pass (the encoder; not the MAE decoder, whose weight gradients run beside the encoder's chain).
         Returns (dx_in f32, dx_in act) or (None, None) when nothing below needs it."""
         k, g = self.k, self.g
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
@@ -388,7 +397,7 @@ class BlockStack:
 
             # One grouped launch for the block's four weight gradients (full-K tiles, no split-K slabs), issued once the
             # whole dgrad chain of the block is enqueued; it runs beside block i-1's chain.
-            grouped = tr and i - lowest >= k.UNGROUP_TAIL and k.can_group_wgrad(M, ((D, Hd), (Hd, D), (D, D), (3 * D, D)))
+            grouped = tr and (not ends_pass or i - lowest >= k.UNGROUP_TAIL) and k.can_group_wgrad(M, ((D, Hd), (Hd, D), (D, D), (3 * D, D)))
             # ---- MLP branch ----
             if tr and not grouped:
                 fork()

@@ -498,7 +498,7 @@ class _MaeFn(torch.autograd.Function):
                         Gd[last]["mlp.fc2.bias"] if tr_d[last] else None, Md, Dd)
         cb_d = (lambda i: sync.block_done("decoder_blocks.", i)) if sync is not None else None
         dxd0, _ = BlockStack(k, gd).backward(ws_d, xd0, Wd, Gd, ws_d.dx[last & 1 ^ 1], ws_d.dx_act[last & 1 ^ 1], True, tr_d,
-                                             True, acc_fn, cb_d)
+                                             True, acc_fn, cb_d, ends_pass=False)
         # -- un-shuffle + decoder_embed
         demb_act = torch.empty(Me, Dd, dtype=k.act_dtype, device=dev)
         # partial rows of the mask-token sum (fixed-order second stage)

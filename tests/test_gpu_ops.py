@@ -595,11 +595,13 @@ def test_registered_torch_ops_forward_and_autograd():
 
 @pytest.mark.parametrize("K,dims", [
     (4032, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),     # ViT-B block: 108 tiles of 256x256
-    (2048 + 64, [(512, 2048), (2048, 512), (512, 512), (1536, 512)]),  # MAE decoder block: 256x128 tiles
+    (2048 + 64, [(512, 2048), (2048, 512), (512, 512), (1536, 512)]),  # MAE decoder block, short K: 256x128 tiles
+    (16384 + 32, [(512, 2048), (2048, 512), (512, 512), (1536, 512)]),  # MAE decoder block, long K: 48 tiles x 4 ragged k-slices
     (2080, [(264, 136), (520, 648)])])                               # ragged tiles in both dimensions
 def test_wgrad_group(K, dims):
-    """pm_wgrad_group: every weight gradient of a block in one launch (full-K tiles, no split-K), store and accumulate,
-    against torch.matmul in f32 on the same bf16 operands; and bit-identical from run to run (no atomics, no slabs)."""
+    """pm_wgrad_group: every weight gradient of a block in one launch (full-K tiles, or k-slices + one reduce launch for a
+    group of few tiles), store and accumulate, against torch.matmul in f32 on the same bf16 operands; and bit-identical from
+    run to run (no atomics: fixed reduction order)."""
     k = _k("bf16")
     bf = torch.bfloat16
     items, want = [], []

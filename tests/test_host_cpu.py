@@ -34,9 +34,10 @@ def test_library_exports_every_declared_symbol(built):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/polypmae.h but not exported"
     from ssl4polyp_amd import _lib
-    assert set(_lib.SIGNATURES) | {"pm_strerror", "pm_abi_version", "pm_gemm_workspace_bytes", "pm_workspace_bytes"} == set(names)
+    assert set(_lib.SIGNATURES) | {"pm_strerror", "pm_abi_version", "pm_gemm_workspace_bytes", "pm_workspace_bytes",
+                                   "pm_wgrad_group_workspace_bytes"} == set(names)
     handle = _lib.load()
-    assert handle.pm_abi_version() == _lib.ABI_VERSION == 3
+    assert handle.pm_abi_version() == _lib.ABI_VERSION == 4
     # nothing undeclared leaves the library: every exported pm_* symbol is in the header (diagnostic hooks included)
     import subprocess
     out = subprocess.run(["nm", "-D", "--defined-only", built], capture_output=True, text=True).stdout
@@ -48,6 +49,19 @@ def test_library_exports_every_declared_symbol(built):
     assert handle.pm_gemm_workspace_bytes(0, 0, _lib.PM_BF16, 12608, 768, 768, None) == 0
     assert handle.pm_workspace_bytes(_lib.WS_LAYERNORM_BWD, 12608, 768) == 1024 * 3 * 768 * 4
     assert handle.pm_strerror(-2).decode() == "unsupported shape"
+    # grouped weight gradients: a ViT-B block (108 tiles) needs no slabs, the MAE decoder block at K = 50 432 tokens is cut
+    # into 4 k-slices (f32 partials + the partial row sums of the two bias gradients); a short K is not sliced
+    def group(dims, biased):
+        arr = (_lib.WgradItem * len(dims))()
+        for j, (o, i) in enumerate(dims):
+            arr[j] = _lib.WgradItem(64, o, 64, i, 64, i, o, i, 0, 64 if j in biased else None)  # (addresses are only checked)
+        return arr
+    enc = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    dec = [(512, 2048), (2048, 512), (512, 512), (1536, 512)]
+    assert handle.pm_wgrad_group_workspace_bytes(group(enc, ()), 4, 12608, _lib.PM_BF16) == 0
+    assert handle.pm_wgrad_group_workspace_bytes(group(dec, (1, 3)), 4, 50432, _lib.PM_BF16) == \
+        4 * 4 * sum(o * i for o, i in dec) + 4 * 4 * (2048 + 1536)
+    assert handle.pm_wgrad_group_workspace_bytes(group(dec, ()), 4, 2112, _lib.PM_BF16) == 0
 
 
 def test_no_cpu_fallback():
