@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--input", choices=["resident", "host"], default="resident",
                     help="resident (the contract: batch already in HBM) or host: uint8 HWC frames in pinned host memory, "
                          "copied and normalised on a side stream each step (PCIe-inclusive rate, DESIGN.md)")
+    ap.add_argument("--preheat", type=float, default=1.0,
+                    help="seconds of untimed steps before the W warm-up steps (clock / power ramp after process start; 0 = none)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step as one hipGraph (auto = off: eager launch keeps up and overlaps the two streams better)")
     return ap.parse_args()
@@ -436,11 +438,30 @@ def run_workload(args, workload, batch, device, world, rank, headline):
         from ssl4polyp_amd.data import DevicePrefetcher
         return DevicePrefetcher([host_pool[i % 4] for i in range(n)], device, flip_p=0.5, generator=host_gen)
 
-    parity = None
-    if rank == 0 and world == 1 and not args.no_parity:
-        # at the freshly initialised weights, before any optimizer step: after tens of AdamW steps at lr 1e-3 on random
-        # labels the network's outputs and gradients collapse towards zero and relative errors stop meaning anything
-        parity = parity_block(workload, model, imgs, labels, args.precision)
+    # The parity block compares at the freshly initialised weights (after tens of AdamW steps at lr 1e-3 on random labels
+    # the outputs and gradients collapse towards zero and relative errors stop meaning anything), but runs AFTER the timed
+    # region on a restored copy of them: its ~10 s of CPU oracle leave the GPU idle, and a timed loop that starts right
+    # after an idle phase measures the clock ramp (first steps up to 1.5x slower) instead of the steady state.
+    want_parity = rank == 0 and world == 1 and not args.no_parity
+    init_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if want_parity else None
+    # Pre-heat: untimed steps of the same step function until args.preheat seconds have passed, so that clocks and power
+    # management have settled before the W warm-up steps (a process that starts timing ~0.15 s after its first launch is
+    # still on the ramp: scratch/host_time.py shows 16 ms steps for the first ~15 steps, 10.8 ms afterwards).
+    preheat_steps = 0
+    if args.preheat > 0 and not host_input:
+        t_ph = time.perf_counter()
+        while True:
+            for _ in range(5):
+                step()
+            preheat_steps += 5
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t_ph
+            if world > 1:  # every rank must leave the loop after the same number of steps (they contain all-reduces)
+                t = torch.tensor([el], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = t.item()
+            if el >= args.preheat:
+                break
     if host_input:
         if use_graph:
             sys.exit("--input host feeds a new batch every step: use eager launch")
@@ -462,13 +483,19 @@ def run_workload(args, workload, batch, device, world, rank, headline):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # one event per step boundary on the step's own stream: the spread of the per-step times (DVFS ramps, a schedule that
+    # settles into a slower phase) is reported beside the mean the metric is computed from
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     if host_input:
-        for im, lb in host_feed(args.steps):
+        for i, (im, lb) in enumerate(host_feed(args.steps)):
             loss = step(im, lb)
+            marks[i + 1].record()
     else:
-        for _ in range(args.steps):
+        for i in range(args.steps):
             loss = step()
+            marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -478,15 +505,24 @@ def run_workload(args, workload, batch, device, world, rank, headline):
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_ms = {"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3), "max": round(per_step[-1], 3),
+               "first": round(marks[0].elapsed_time(marks[1]), 3), "last": round(marks[-2].elapsed_time(marks[-1]), 3)}
     loss_val = float(loss.detach())
     if not (loss_val == loss_val):
         sys.exit("non-finite loss in the timed region")
     rec = None
     stats = None
+    parity = None
     if not args.no_kernel_stats:
         # EVERY rank runs the instrumented steps (they contain the gradient all-reduces: a rank that skipped them would
         # leave the others waiting in RCCL); only rank 0 reports
         stats = kernel_stats(model, eager_step)
+    if want_parity:
+        model._rt.wait_updates()
+        torch.cuda.synchronize()
+        model.load_state_dict(init_state)  # back to the initial weights (the optimizer state is not used by the comparison)
+        parity = parity_block(workload, model, imgs, labels, args.precision)
     if rank == 0:
         ips = batch * world * args.steps / dt
         per_gpu_tflops = ips / world * GFLOP_PER_IMG[workload] / 1e3
@@ -516,7 +552,7 @@ def run_workload(args, workload, batch, device, world, rank, headline):
             roof["hbm_kernels"] = hb        # in-step (beside the weight-gradient stream), algorithmic bytes / time
             roof["gemm_share_of_step"] = round(gt / (dt / args.steps), 3)
         rec = {"value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "host_enqueue_ms_per_step": round(t_enq * 1e3, 3),
+               "host_enqueue_ms_per_step": round(t_enq * 1e3, 3), "step_ms": step_ms, "preheat_steps": preheat_steps,
                "config": {"workload": WORKLOAD_NAME[workload] + f", bs={batch}/GPU, 224^2, AdamW, random init",
                           "global_batch": batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
                           "launch": "hipGraph replay" if use_graph else "eager",
@@ -566,7 +602,8 @@ def main():
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic" if args.input == "resident" else "synthetic uint8 frames in pinned host memory (PCIe-inclusive)",
-            "config": head["config"], "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
+            "config": head["config"], "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"], "step_ms": head["step_ms"],
+            "preheat_steps": head["preheat_steps"],
             "roofline": head["roofline"],
         }
         if "parity" in head:
