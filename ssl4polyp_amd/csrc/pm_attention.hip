@@ -524,7 +524,14 @@ template <int DH, int NT>
 __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ out,
                                                                 const __bf16* __restrict__ dout,
                                                                 const float* __restrict__ lse, __bf16* __restrict__ dqkv,
-                                                                int N, int H, float scale) {
+                                                                int N, int H, float scale
+#ifdef PM_ATTN_DEBUG
+                                                                , int dbg  // diagnostic build: bit 0 skips pass 1, bit 1 pass 2
+#endif
+                                                                ) {
+#ifndef PM_ATTN_DEBUG
+  constexpr int dbg = 0;
+#endif
   using T = __bf16;
   constexpr int RB = DH * 2;
   constexpr int IMG = NT * 32 * RB;
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* _
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
 #pragma unroll (DH == 32 ? 2 : 1)
-    for (int kt = 0; kt < NT; ++kt) {
+    for (int kt = 0; kt < ((dbg & 1) ? 0 : NT); ++kt) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
@@ -637,7 +644,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* _
       dv[dt] = zero16();
     }
 #pragma unroll (DH == 32 ? 2 : 1)
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < ((dbg & 2) ? 0 : NT); ++qt) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
@@ -679,8 +686,14 @@ int launch_bwd_fused(const void* qkv, const void* out, const void* dout, const f
   const float scale = 1.0f / sqrtf((float)DH);
   auto kern = attn_bwd_fused_kernel<DH, NT>;
   PM_ALLOW_LDS(kern, lds);
+#ifdef PM_ATTN_DEBUG
+  static const int dbg = [] { const char* e = getenv("PM_ATTN_BWD_SKIP"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(NT * 64), lds, s, (const __bf16*)qkv, (const __bf16*)out, (const __bf16*)dout, lse,
+                     (__bf16*)dqkv, N, H, scale, dbg);
+#else
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(NT * 64), lds, s, (const __bf16*)qkv, (const __bf16*)out, (const __bf16*)dout, lse,
                      (__bf16*)dqkv, N, H, scale);
+#endif
   return pm_check_launch();
 }
 
