@@ -37,6 +37,7 @@ PEAK_HBM_GBPS = 8000.0                         # MI355X_MICROARCH.md: HBM3E
 # AdamW on the side stream beside the next forward: +0.5..1 % on the fine-tune step (its forward is MFMA-bound), -1.3 % on the
 # MAE step (its encoder forward on 50 tokens is short and HBM-hungry itself); PM_OVERLAP_ADAMW=0/1 forces either
 OVERLAP_ADAMW = {"cls": os.environ.get("PM_OVERLAP_ADAMW", "1") != "0", "mae": os.environ.get("PM_OVERLAP_ADAMW", "0") != "0"}
+MAE_IT_PER_EPOCH = 390  # ~100 k unlabelled frames / 256 per step
 WORKLOAD_NAME = {"cls": "ViT-B/16 classification fine-tune", "mae": "MAE pre-train ViT-B/16 mask 0.75"}
 
 
@@ -109,7 +110,17 @@ def make_step(workload, ddp, opt, imgs, labels, lr_every_step=False):
     counter = [0]
 
     def touch_lr():
-        if lr_every_step:  # engine_pretrain.py:47-48: a new lr before every iteration
+        if workload == "mae":
+            # engine_pretrain.py:47-48: lr_sched.adjust_learning_rate(optimizer, data_iter_step / len(data_loader) + epoch)
+            # before EVERY iteration -- the reference's 40 warm-up epochs (main_pretrain.py:78-79), MAE_IT_PER_EPOCH iterations
+            # each.  At a constant 1e-3 from step 0 the pre-train diverges after a few hundred steps (non-finite loss at
+            # --steps 400); the kernels do the same work whatever the value in the device-side hyper-parameter slot.
+            from ssl4polyp_amd.train import mae_lr
+            f = mae_lr(counter[0] / MAE_IT_PER_EPOCH, 1.0, 0.0, 40, 400)
+            counter[0] += 1
+            for g, b in zip(opt.param_groups, base_lr):
+                g["lr"] = b * f
+        elif lr_every_step:  # the fine-tune schedule steps per epoch (tc.py:3952-3957); this flag changes lr every step anyway
             counter[0] += 1
             f = 1.0 - 1e-4 * (counter[0] % 7)
             for g, b in zip(opt.param_groups, base_lr):
@@ -556,7 +567,8 @@ def run_workload(args, workload, batch, device, world, rank, headline):
                "config": {"workload": WORKLOAD_NAME[workload] + f", bs={batch}/GPU, 224^2, AdamW, random init",
                           "global_batch": batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
                           "launch": "hipGraph replay" if use_graph else "eager",
-                          "lr_schedule": "new lr every step" if args.lr_every_step else "constant"},
+                          "lr_schedule": ("per-iteration warm-up (engine_pretrain.py:47-48; 40 epochs x 390 it)" if workload == "mae"
+                                          else "new lr every step" if args.lr_every_step else "constant")},
                "roofline": roof}
         if parity is not None:
             rec["parity"] = parity
