@@ -206,7 +206,9 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 
 // f32x4 forms used by the GEMM epilogues
 __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
-#ifdef PM_GELU_SCALAR  // A/B build (scratch/build_alt.sh): one value at a time
+#ifdef PM_GELU_IDENTITY  // diagnostic build: what the epilogue costs without its exp / rcp (results are wrong)
+  return v * 0.5f;
+#elif defined(PM_GELU_SCALAR)  // A/B build (scratch/build_alt.sh): one value at a time
   return f32x4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
 #else
   const f32x2 a = gelu_erf2(f32x2{v[0], v[1]}), b = gelu_erf2(f32x2{v[2], v[3]});
@@ -214,7 +216,9 @@ __device__ __forceinline__ f32x4 gelu_erf4(f32x4 v) {
 #endif
 }
 __device__ __forceinline__ f32x4 gelu_erf_grad4(f32x4 v) {
-#ifdef PM_GELU_SCALAR
+#ifdef PM_GELU_IDENTITY
+  return v * 0.5f;
+#elif defined(PM_GELU_SCALAR)
   return f32x4{gelu_erf_grad(v[0]), gelu_erf_grad(v[1]), gelu_erf_grad(v[2]), gelu_erf_grad(v[3])};
 #else
   const f32x2 a = gelu_erf_grad2(f32x2{v[0], v[1]}), b = gelu_erf_grad2(f32x2{v[2], v[3]});
