@@ -150,6 +150,8 @@ def kernel_stats(model, step):
     """Per-launch HIP-event timing of the GEMMs, LayerNorms and attention calls of one step (events recorded on the stream
     each kernel is launched on)."""
     k = model._rt.k
+    block_calls = k.BLOCK_CALLS
+    k.BLOCK_CALLS = False  # the instrumented steps issue every forward kernel as its own call (same launches), so the hooks see them
     orig = dict(gemm=k.gemm, lnf=k.layernorm_fwd, lnb=k.layernorm_bwd, af=k.attention_fwd, ab=k.attention_bwd, wg=k.wgrad_group)
     rec, hbm, att = [], [], []
     act_b = 2 if k.precision == "bf16" else 4
@@ -199,6 +201,7 @@ def kernel_stats(model, step):
     finally:
         k.gemm, k.layernorm_fwd, k.layernorm_bwd = orig["gemm"], orig["lnf"], orig["lnb"]
         k.attention_fwd, k.attention_bwd, k.wgrad_group = orig["af"], orig["ab"], orig["wg"]
+        k.BLOCK_CALLS = block_calls
 
     def fold(items, unit):
         d = {}

@@ -202,6 +202,77 @@ int pm_cast(const float* src, void* dst, int dst_dtype, long n, void* stream);
 int pm_preprocess_u8(const unsigned char* src, const unsigned char* flip_flags, float* dst, int B, int H, int W,
                      float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
 
+/* One transformer block forward for one range of samples in ONE call (timm Block: models_mae.py:39-41,53-55,166-167,
+ * 186-187; models.py:122-123,204-205):  x_mid = x + proj(attn(LN1 x));  x_out = x_mid + fc2(gelu(fc1(LN2 x_mid))).
+ * Host-side composition of pm_layernorm_fwd / pm_gemm_ex / pm_attention_fwd on `stream`, launch for launch what a caller
+ * would issue itself -- for hosts where ~27 separate calls per block cost more than the block takes to run.  Every
+ * pointer addresses row 0 of the range (rows = samples * N tokens); buffers are the saved-for-backward activations:
+ * ln1 / qkv [rows, 3D] / attn / ln2 / h_pre / h_act [rows, Hd] act-typed, x / x_mid / x_out f32 [rows, D], mean / rstd f32
+ * [rows], lse f32 [samples * heads * N].  The descriptor is plain data: build it once, keep it, pass it every step. */
+typedef struct pm_block_fwd_desc {
+  const float* x;
+  float* x_mid;
+  float* x_out;
+  void* ln1;
+  float* mean1;
+  float* rstd1;
+  void* qkv;
+  float* lse;
+  void* attn;
+  void* ln2;
+  float* mean2;
+  float* rstd2;
+  void* h_pre;
+  void* h_act;
+  const float *norm1_w, *norm1_b, *norm2_w, *norm2_b;  /* f32 [D] */
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;          /* act-typed [out, in] as nn.Linear stores them */
+  const float *qkv_b, *proj_b, *fc1_b, *fc2_b;         /* f32 */
+  int rows, samples, N, D, Hd, heads;
+  int dtype;        /* PM_BF16 / PM_F32: activation and matrix type */
+  int gemm_variant; /* pm_gemm_opts.variant for the four GEMMs (0 = the dispatcher's heuristics) */
+  float eps;
+} pm_block_fwd_desc;
+int pm_vit_block_fwd(const pm_block_fwd_desc* d, void* stream);
+
+/* The backward of that block in ONE call (autograd of the timm Block through engine_pretrain.py:65 / tc.py:4533), for a
+ * fully trainable block whose four weight gradients fit pm_wgrad_group:
+ *   on `stream`:       [wait ev_join]  dfc2 (dGELU) -> dfc1 -> LN2' -> dproj -> attention' -> dqkv -> LN1'
+ *   on `side_stream`:  after ev_fork (recorded behind attention'): pm_wgrad_group(fc2, fc1 + bias, proj, qkv + bias) -> ev_done
+ * dx / dx_act: gradient of the block output (f32 + act copy); dmid / dmid_act: residual gradient between the branches;
+ * din / din_act: gradient of the block input (outputs).  Vector gradients are += targets; g_below_bias receives the column
+ * sums of din (bias gradient of the Linear that produced the block input), NULL when there is none; accumulate bit j
+ * (0 qkv, 1 proj, 2 fc1, 3 fc2): dW += instead of dW =.  ev_join (optional), ev_fork, ev_done are hipEvent_t of the caller:
+ * ev_done fires when this block's matrix gradients are final and its operands may be overwritten.  The library creates,
+ * keeps and frees nothing.  Returns the status of the first failing launch (PM_ESHAPE from pm_wgrad_group: the caller falls
+ * back to per-kernel calls before anything was enqueued on the side stream -- check shapes with
+ * pm_wgrad_group_workspace_bytes / the admission rules first). */
+typedef struct pm_block_bwd_desc {
+  const float* x_in;
+  const float* x_mid;
+  const void *ln1, *qkv, *attn, *ln2, *h_pre, *h_act;
+  const float *mean1, *rstd1, *mean2, *rstd2, *lse;
+  const float *norm1_w, *norm2_w;
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+  const float* dx;
+  const void* dx_act;
+  float* dmid;
+  void* dmid_act;
+  float* din;
+  void* din_act;
+  void *d_hidden, *d_qkv, *d_ln, *d_attn;
+  float* delta;
+  float *g_norm1_w, *g_norm1_b, *g_norm2_w, *g_norm2_b;
+  float *g_qkv_w, *g_proj_w, *g_fc1_w, *g_fc2_w;
+  float *g_qkv_b, *g_proj_b, *g_fc1_b, *g_below_bias;
+  void* ws_ln;
+  size_t ws_ln_bytes;
+  void* ws_group;
+  size_t ws_group_bytes;
+  void *side_stream, *ev_join, *ev_fork, *ev_done;
+  int samples, N, D, Hd, heads, dtype, gemm_variant, group_blocks, accumulate;
+} pm_block_bwd_desc;
+int pm_vit_block_bwd(const pm_block_bwd_desc* d, void* stream);
+
 /* Top of the fine-tune forward (models.py:127,134-139 / 209,216-221): final LayerNorm, token selection, lin_head.
  *   pool = 0 (out_token "cls"):     feat[b] = LN(x[b, 0])                 (only row 0 is normalised)
  *   pool = 1 (out_token "spatial"): feat[b] = mean_{n >= 1} LN(x[b, n])   (x[:, 1:].mean(1))

@@ -21,6 +21,8 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     "pm_layernorm_fwd": [P, L, P, P, P, I, P, P, I, I, F, P],
     "pm_layernorm_bwd": [P, I, P, L, P, P, P, P, L, P, L, P, I, P, P, P, I, I, P, ctypes.c_size_t, P],
+    "pm_vit_block_fwd": [P, P],
+    "pm_vit_block_bwd": [P, P],
     "pm_gemm": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P],
     "pm_gemm_ws": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P],
     "pm_gemm_ex": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P, P],
@@ -53,7 +55,7 @@ SIGNATURES = {
     "pm_grad_stats": [P, L, P, P],
 }
 
-ABI_VERSION = 4  # pm_abi_version() of the library these signatures describe
+ABI_VERSION = 5  # pm_abi_version() of the library these signatures describe
 
 WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4
 
@@ -67,6 +69,27 @@ class WgradItem(ctypes.Structure):
     """pm_wgrad_item of include/polypmae.h."""
     _fields_ = [("dY", c_void_p), ("lddy", c_long), ("X", c_void_p), ("ldx", c_long), ("dW", c_void_p), ("lddw", c_long),
                 ("n_out", c_int), ("n_in", c_int), ("accumulate", c_int), ("dbias", c_void_p)]
+
+
+class BlockBwdDesc(ctypes.Structure):
+    """pm_block_bwd_desc of include/polypmae.h."""
+    _fields_ = ([(n, c_void_p) for n in ("x_in", "x_mid", "ln1", "qkv", "attn", "ln2", "h_pre", "h_act", "mean1", "rstd1", "mean2",
+                                        "rstd2", "lse", "norm1_w", "norm2_w", "qkv_w", "proj_w", "fc1_w", "fc2_w", "dx", "dx_act",
+                                        "dmid", "dmid_act", "din", "din_act", "d_hidden", "d_qkv", "d_ln", "d_attn", "delta",
+                                        "g_norm1_w", "g_norm1_b", "g_norm2_w", "g_norm2_b", "g_qkv_w", "g_proj_w", "g_fc1_w",
+                                        "g_fc2_w", "g_qkv_b", "g_proj_b", "g_fc1_b", "g_below_bias")] +
+                [("ws_ln", c_void_p), ("ws_ln_bytes", ctypes.c_size_t), ("ws_group", c_void_p), ("ws_group_bytes", ctypes.c_size_t)] +
+                [(n, c_void_p) for n in ("side_stream", "ev_join", "ev_fork", "ev_done")] +
+                [(n, c_int) for n in ("samples", "N", "D", "Hd", "heads", "dtype", "gemm_variant", "group_blocks", "accumulate")])
+
+
+class BlockFwdDesc(ctypes.Structure):
+    """pm_block_fwd_desc of include/polypmae.h."""
+    _fields_ = ([(n, c_void_p) for n in ("x", "x_mid", "x_out", "ln1", "mean1", "rstd1", "qkv", "lse", "attn", "ln2", "mean2",
+                                        "rstd2", "h_pre", "h_act", "norm1_w", "norm1_b", "norm2_w", "norm2_b", "qkv_w", "proj_w",
+                                        "fc1_w", "fc2_w", "qkv_b", "proj_b", "fc1_b", "fc2_b")] +
+                [(n, c_int) for n in ("rows", "samples", "N", "D", "Hd", "heads", "dtype", "gemm_variant")] +
+                [("eps", ctypes.c_float)])
 
 
 PM_ESHAPE = -2

@@ -158,6 +158,7 @@ class Kernels:
         """dx[M,K_in] = dy[M,N_out] @ W[N_out,K_in]  (W read as stored: k-major B operand); colsum += column sums of dx."""
         self.gemm(dy, N_out, 0, W, K_in, 1, None, dx, K_in, epilogue, M, K_in, N_out, aux=aux, colsum=colsum)
 
+    BLOCK_CALLS = os.environ.get("PM_BLOCK_CALLS", "1") != "0"  # block forward as ONE C call (pm_vit_block_fwd) instead of seven
     GROUP_WGRAD = os.environ.get("PM_GROUP_WGRAD", "1") != "0"  # A/B switch: one grouped weight-gradient launch per block
     GROUP_BLOCKS = int(os.environ.get("PM_GROUP_BLOCKS", "0"))  # CUs the grouped launch may take (0 = one workgroup per tile)
     GROUP_MIN_TILES = int(os.environ.get("PM_GROUP_MIN_TILES", "64"))
@@ -319,6 +320,12 @@ class BlockStack:
             parts = [((main if j == 0 else auxs[j - 1]), cuts[j], cuts[j + 1]) for j in range(nparts)]
         else:
             parts = [(None, 0, B)]
+        # PM_BLOCK_CALLS=0: every kernel of a block as its own C call from Python (the same launches; A/B and a fallback)
+        fast = k.BLOCK_CALLS and x_in.is_cuda
+        if fast:
+            lib = k.lib
+            cache = ws.__dict__.setdefault("_fwd_descs", {})
+            raw = [(st.cuda_stream if st is not None and st is not main else None) for st, _, _ in parts]
         x = x_in
         for i in range(g.depth):
             if before_block is not None:
@@ -327,6 +334,18 @@ class BlockStack:
                 else:
                     before_block(i)
             bw, p = ws.block(i), W[i]
+            if fast:
+                # one C call per (block, sample range): pm_vit_block_fwd issues the same seven launches from a descriptor that
+                # is built once and kept (every buffer it names is persistent: workspace, flat parameters, bf16 shadow)
+                for j, (st, b0, b1) in enumerate(parts):
+                    key = (b0, b1, x.data_ptr(), p["attn.qkv.weight"].data_ptr(), p["norm1.weight"].data_ptr(), k.gemm_variant)
+                    ent = cache.get((i, j))
+                    if ent is None or ent[0] != key:
+                        ent = cache[(i, j)] = (key, self._fwd_desc(ws, bw, p, x, b0, b1))
+                    _lib.check(lib.pm_vit_block_fwd(ctypes.byref(ent[1]), raw[j] if raw[j] is not None else _stream()),
+                               "pm_vit_block_fwd")
+                x = bw.x_out
+                continue
             for st, b0, b1 in parts:
                 r0, r1, Bh = b0 * N, b1 * N, b1 - b0
                 Mh = r1 - r0
@@ -353,6 +372,49 @@ class BlockStack:
                 main.wait_event(ev)
         return x
 
+    def _fwd_desc(self, ws: StackWorkspace, bw: BlockWorkspace, p, x: torch.Tensor, b0: int, b1: int):
+        """pm_block_fwd_desc of block `bw` for samples [b0, b1): every pointer at the first row of the range."""
+        k, g = self.k, self.g
+        N, D, Hd = ws.N, g.dim, g.hidden
+        r0, h0 = b0 * N, b0 * g.heads * N
+        a = lambda t, row, width: t.data_ptr() + row * width * t.element_size()
+        v = lambda t: t.data_ptr() if t is not None else None
+        return _lib.BlockFwdDesc(
+            a(x, r0, D), a(bw.x_mid, r0, D), a(bw.x_out, r0, D), a(bw.ln1, r0, D), a(bw.mean1, r0, 1), a(bw.rstd1, r0, 1),
+            a(bw.qkv, r0, 3 * D), a(bw.lse, h0, 1), a(bw.attn, r0, D), a(bw.ln2, r0, D), a(bw.mean2, r0, 1), a(bw.rstd2, r0, 1),
+            a(bw.h_pre, r0, Hd), a(bw.h_act, r0, Hd),
+            v(p["norm1.weight"]), v(p["norm1.bias"]), v(p["norm2.weight"]), v(p["norm2.bias"]),
+            v(p["attn.qkv.weight"]), v(p["attn.proj.weight"]), v(p["mlp.fc1.weight"]), v(p["mlp.fc2.weight"]),
+            v(p["attn.qkv.bias"]), v(p["attn.proj.bias"]), v(p["mlp.fc1.bias"]), v(p["mlp.fc2.bias"]),
+            (b1 - b0) * N, b1 - b0, N, D, Hd, g.heads, k.act, k.gemm_variant, k.eps)
+
+    def _bwd_desc(self, ws, bw, p, gr, xin, dx, dx_act, dmid, dmid_act, din, din_act, d_hidden, d_qkv, below_bias, acc, side, main):
+        """(pm_block_bwd_desc, done event, objects to keep alive) of one block: the events are created once and reused."""
+        k, g = self.k, self.g
+        M, D, Hd = ws.M, g.dim, g.hidden
+        v = lambda t: t.data_ptr() if t is not None else None
+        ws_ln = k._scratch("_ws_ln", k._need(("ln", M, D), lambda: k.lib.pm_workspace_bytes(_lib.WS_LAYERNORM_BWD, M, D)), dx.device)
+        items = (_lib.WgradItem * 4)()
+        for j, (n_out, n_in, bias) in enumerate(((D, Hd, False), (Hd, D, True), (D, D, False), (3 * D, D, True))):
+            items[j] = _lib.WgradItem(64, n_out, 64, n_in, 64, n_in, n_out, n_in, 0, 64 if bias else None)  # (sizes only)
+        need = k._need(("groupws", M, k.act, D, Hd), lambda: k.lib.pm_wgrad_group_workspace_bytes(items, 4, M, k.act))
+        ws_group = k._scratch("_ws_group", need, dx.device) if need else None
+        ev_fork, ev_done = torch.cuda.Event(), torch.cuda.Event()
+        ev_fork.record(main)   # (materialises the hipEvent_t handles; re-recorded by every call)
+        ev_done.record(main)
+        desc = _lib.BlockBwdDesc(
+            v(xin), v(bw.x_mid), v(bw.ln1), v(bw.qkv), v(bw.attn), v(bw.ln2), v(bw.h_pre), v(bw.h_act), v(bw.mean1), v(bw.rstd1),
+            v(bw.mean2), v(bw.rstd2), v(bw.lse), v(p["norm1.weight"]), v(p["norm2.weight"]), v(p["attn.qkv.weight"]),
+            v(p["attn.proj.weight"]), v(p["mlp.fc1.weight"]), v(p["mlp.fc2.weight"]), v(dx), v(dx_act), v(dmid), v(dmid_act), v(din),
+            v(din_act), v(d_hidden), v(d_qkv), v(ws.d_ln), v(ws.d_attn), v(ws.delta),
+            v(gr["norm1.weight"]), v(gr["norm1.bias"]), v(gr["norm2.weight"]), v(gr["norm2.bias"]), v(gr["attn.qkv.weight"]),
+            v(gr["attn.proj.weight"]), v(gr["mlp.fc1.weight"]), v(gr["mlp.fc2.weight"]), v(gr["attn.qkv.bias"]),
+            v(gr["attn.proj.bias"]), v(gr["mlp.fc1.bias"]), v(below_bias),
+            v(ws_ln), ws_ln.numel(), v(ws_group), ws_group.numel() if ws_group is not None else 0,
+            side.cuda_stream, None, ev_fork.cuda_event, ev_done.cuda_event,
+            ws.B, ws.N, D, Hd, g.heads, k.act, k.gemm_variant, k.GROUP_BLOCKS, acc)
+        return desc, ev_done, (ev_fork, ws_ln, ws_group)
+
     def backward(self, ws: StackWorkspace, x_in: torch.Tensor, W, G, dx: torch.Tensor, dx_act: torch.Tensor,
                  last_bias_grad_done: bool, trainable: Sequence[bool], need_input_grad: bool,
                  accumulate: Callable[[str, int], bool], on_block_done: Optional[Callable[[int], None]] = None,
@@ -375,6 +437,11 @@ class BlockStack:
             for j in sorted((j for j in pending if j >= down_to), reverse=True):
                 main.wait_event(pending.pop(j))
 
+        # PM_BLOCK_CALLS: fully trainable, grouped blocks go through pm_vit_block_bwd (one C call per block)
+        fast = (k.BLOCK_CALLS and k.GROUP_BIAS and not k.FUSE_COLSUM and dx.is_cuda and
+                not torch.cuda.is_current_stream_capturing())
+        bcache = ws.__dict__.setdefault("_bwd_descs", {})
+        ptr_of = lambda t: t.data_ptr() if t is not None else 0
         for i in reversed(range(g.depth)):
             if i < lowest and not need_input_grad:
                 join(0)
@@ -407,6 +474,28 @@ class BlockStack:
             # One grouped launch for the block's four weight gradients (full-K tiles, no split-K slabs), issued once the
             # whole dgrad chain of the block is enqueued; it runs beside block i-1's chain.
             grouped = tr and (not ends_pass or i - lowest >= k.UNGROUP_TAIL) and k.can_group_wgrad(M, ((D, Hd), (Hd, D), (D, D), (3 * D, D)))
+            if grouped and fast:
+                # the whole block in ONE C call (pm_vit_block_bwd): the same launches, the same fork / done events, from a
+                # descriptor built once per block and kept (every buffer it names is persistent)
+                below_bias = (G[i - 1]["mlp.fc2.bias"] if trainable[i - 1] else None) if i > 0 else prev_bias_grad
+                acc = (int(accumulate("attn.qkv.weight", i)) | int(accumulate("attn.proj.weight", i)) << 1 |
+                       int(accumulate("mlp.fc1.weight", i)) << 2 | int(accumulate("mlp.fc2.weight", i)) << 3)
+                key = (dx.data_ptr(), dx_act.data_ptr(), xin.data_ptr(), gr["attn.qkv.weight"].data_ptr(),
+                       p["attn.qkv.weight"].data_ptr(), gr["norm1.weight"].data_ptr(),
+                       below_bias.data_ptr() if below_bias is not None else 0, acc, k.gemm_variant, k.GROUP_BLOCKS,
+                       ptr_of(k.__dict__.get("_ws_ln")), ptr_of(k.__dict__.get("_ws_group")))  # (scratch is replaced when it grows)
+                ent = bcache.get(i)
+                if ent is None or ent[0] != key:
+                    ent = bcache[i] = (key,) + self._bwd_desc(ws, bw, p, gr, xin, dx, dx_act, dmid, dmid_act, din, din_act,
+                                                              d_hidden, d_qkv, below_bias, acc, side, main)
+                _, desc, ev_done, keep = ent
+                _lib.check(k.lib.pm_vit_block_bwd(ctypes.byref(desc), _stream()), "pm_vit_block_bwd")
+                pending[i] = ev_done
+                if on_block_done is not None:
+                    with torch.cuda.stream(side):
+                        on_block_done(i)
+                dx, dx_act = din, din_act
+                continue
             # ---- MLP branch ----
             if tr and not grouped:
                 fork()
