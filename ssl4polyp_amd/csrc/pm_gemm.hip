@@ -1420,15 +1420,13 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
       case 24: return launch_v3<256, 256, 2, 4, 4, 2, false, false, 8, true>(a, b_kmajor, s);
       case 25: return launch_v3<256, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);
       case 26: return launch_v3<192, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);
-      // two 4-wave blocks per CU (128x256 tiles, 3-slot ring): measured slower everywhere, kept for the record
-      case 27: return launch_v3<128, 256, 2, 2, 3, 2, false, false, 4, true>(a, b_kmajor, s);
-      // two 8-wave blocks per CU (64x64 per wave, <= 128 VGPRs, 3-slot ring = 72 KiB): one block's prologue / epilogue
-      // under the other's k-loop, at 85 instead of 128 FLOP per LDS-fill byte
-      // (one wave per SIMD -- launch_v3<256, 256, 2, 2, 4, 1, true, false, 4, true>: 4 waves, 128x128 per wave, 512 VGPRs,
-      //  2/3 of the LDS reads per FLOP -- equals the 8-wave loop on long-K dgrads (decoder dfc1 1.0 PFLOP/s both) and
-      //  loses 5-30 % wherever prologue / epilogue matter: not instantiated)
-      case 28: return launch_v3<256, 128, 4, 2, 3, 4, true>(a, b_kmajor, s);
-      case 29: return launch_v3<128, 256, 2, 4, 3, 4, true>(a, b_kmajor, s);
+      // Measured and no longer instantiated (the template still admits them):
+      //   two 4-wave blocks per CU   launch_v3<128, 256, 2, 2, 3, 2, false, false, 4, true>   slower on every shape
+      //   two 8-wave blocks per CU   launch_v3<256, 128, 4, 2, 3, 4, true> / <128, 256, 2, 4, 3, 4, true>: <= 128 VGPRs, 100-150
+      //                              spills, 85 instead of 128 FLOP per LDS-fill byte: 1.7x slower
+      //   one wave per SIMD          launch_v3<256, 256, 2, 2, 4, 1, true, false, 4, true>: 128x128 per wave, 512 VGPRs, 2/3 of the
+      //                              LDS reads per FLOP: equals the 8-wave loop on long-K dgrads (decoder dfc1 1.0 PFLOP/s both),
+      //                              loses 5-30 % wherever prologue / epilogue matter
       default: return launch_v3<256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
     }
   }
