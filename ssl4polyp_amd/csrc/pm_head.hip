@@ -305,9 +305,8 @@ __global__ __launch_bounds__(256) void spatial_head_bwd_kernel(const float* __re
   }
 }
 
-// Parameter gradients of the head (lin_head weight / bias, final-norm gamma / beta): one thread per column walks the
-// samples in order -- a fixed summation order instead of one float atomic per (sample, column), so the whole training
-// step is reproducible bit for bit (B * (n_class + 3) loads per thread: a few microseconds).
+// Parameter gradients of the head (lin_head weight / bias, final-norm gamma / beta): one lane per column, a fixed summation
+// order instead of one float atomic per (sample, column), so the whole training step is reproducible bit for bit.
 // xhat_mean != NULL (spatial pooling): the pooled xhat saved by the forward; else xhat of the cls row from x / mean / rstd.
 __global__ __launch_bounds__(256) void head_pgrad_kernel(const float* __restrict__ dlogits, const float* __restrict__ dfeat,
                                                          const float* __restrict__ x, long sample_stride,
@@ -316,25 +315,54 @@ __global__ __launch_bounds__(256) void head_pgrad_kernel(const float* __restrict
                                                          const float* __restrict__ rstd, float* __restrict__ dW,
                                                          float* __restrict__ dbias, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, int B, int D, int n_class) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d < D) {
-    if (dgamma || dbeta) {
-      float sg = 0.f, sb = 0.f;
-      for (int b = 0; b < B; ++b) {
-        const float g = feat_grad(dfeat, dlogits, W, b, d, D, n_class);
-        const float xh = xhat_mean ? xhat_mean[(long)b * D + d] : (x[(long)b * sample_stride + d] - mean[b]) * rstd[b];
-        sg += g * xh;
-        sb += g;
+  // 64 columns per block; the four waves take every fourth sample (the cls rows are one sample = 600 KB apart: a thread
+  // that walks all B serially pays B load latencies -- 55 us at B = 64 at the very start of the backward pass), two
+  // independent accumulator pairs per wave, partials combined in wave order through LDS: a fixed summation order.
+  __shared__ float part[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + lane;
+  const bool live = d < D;
+  if (dgamma || dbeta) {
+    float g0 = 0.f, b0 = 0.f, g1 = 0.f, b1 = 0.f;
+    if (live) {
+      int b = wave;
+      for (; b + 4 < B; b += 8) {
+        const float ga = feat_grad(dfeat, dlogits, W, b, d, D, n_class), gb = feat_grad(dfeat, dlogits, W, b + 4, d, D, n_class);
+        const float xa = xhat_mean ? xhat_mean[(long)b * D + d] : (x[(long)b * sample_stride + d] - mean[b]) * rstd[b];
+        const float xb = xhat_mean ? xhat_mean[(long)(b + 4) * D + d]
+                                   : (x[(long)(b + 4) * sample_stride + d] - mean[b + 4]) * rstd[b + 4];
+        g0 += ga * xa; b0 += ga;
+        g1 += gb * xb; b1 += gb;
       }
-      if (dgamma) dgamma[d] += sg;
-      if (dbeta) dbeta[d] += sb;
+      for (; b < B; b += 4) {
+        const float ga = feat_grad(dfeat, dlogits, W, b, d, D, n_class);
+        const float xa = xhat_mean ? xhat_mean[(long)b * D + d] : (x[(long)b * sample_stride + d] - mean[b]) * rstd[b];
+        g0 += ga * xa; b0 += ga;
+      }
     }
-    if (dW) {
-      for (int k = 0; k < n_class; ++k) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dlogits[(long)b * n_class + k] * feat[(long)b * D + d];
-        dW[(long)k * D + d] += s;
+    part[0][wave][lane] = g0 + g1;
+    part[1][wave][lane] = b0 + b1;
+    __syncthreads();
+    if (wave == 0 && live) {
+      if (dgamma) dgamma[d] += (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
+      if (dbeta) dbeta[d] += (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]);
+    }
+  }
+  if (dW) {  // per class: the waves split the samples as above, partials combined in wave order
+    for (int k = 0; k < n_class; ++k) {
+      float s0 = 0.f, s1 = 0.f;
+      if (live) {
+        int b = wave;
+        for (; b + 4 < B; b += 8) {
+          s0 += dlogits[(long)b * n_class + k] * feat[(long)b * D + d];
+          s1 += dlogits[(long)(b + 4) * n_class + k] * feat[(long)(b + 4) * D + d];
+        }
+        for (; b < B; b += 4) s0 += dlogits[(long)b * n_class + k] * feat[(long)b * D + d];
       }
+      __syncthreads();  // (the previous round's partials have been read)
+      part[0][wave][lane] = s0 + s1;
+      __syncthreads();
+      if (wave == 0 && live) dW[(long)k * D + d] += (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
     }
   }
   if (dbias && blockIdx.x == 0 && threadIdx.x < n_class) {
@@ -457,7 +485,7 @@ extern "C" int pm_vit_head_bwd(const float* dlogits, const float* dfeat, const f
 #undef PM_HEAD_BWD
   }
   if (dW || dbias || dgamma || dbeta)
-    hipLaunchKernelGGL(head_pgrad_kernel, dim3((D + 255) / 256), dim3(256), 0, s, dlogits, dfeat, x, (long)N * D, W, feat,
+    hipLaunchKernelGGL(head_pgrad_kernel, dim3((D + 63) / 64), dim3(256), 0, s, dlogits, dfeat, x, (long)N * D, W, feat,
                        pool == 1 ? xhat_mean : nullptr, mean, rstd, dW, dbias, dgamma, dbeta, B, D, n_class);
   return pm_check_launch();
 }
