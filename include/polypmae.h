@@ -172,7 +172,8 @@ int pm_mae_masking(const float* noise, int* ids_shuffle, int* ids_restore, float
 int pm_mae_unshuffle(const float* emb, const float* mask_token, const float* dpos, const int* ids_restore, float* out,
                      int B, int L, int keep, int D, void* stream);
 /* Backward: demb act-typed [B,1+keep,D] (pure gather through ids_shuffle); dmask_token f32 [D] (+=).
- * workspace (>= 128*D*4 bytes) makes the mask-token sum two-stage and deterministic; NULL falls back to float atomics. */
+ * workspace (pm_workspace_bytes(PM_WS_UNSHUFFLE_BWD, M, D) = 1024*D*4 bytes) makes the mask-token sum two-stage and deterministic;
+ * NULL (or less than rows*D*4 for the launch's block rows) falls back to float atomics. */
 int pm_mae_unshuffle_bwd(const float* dout, const int* ids_shuffle, void* demb, int act_dtype, float* dmask_token,
                          int B, int L, int keep, int D, void* workspace, size_t ws_bytes, void* stream);
 

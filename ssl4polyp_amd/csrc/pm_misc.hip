@@ -491,7 +491,7 @@ extern "C" size_t pm_workspace_bytes(int kind, int M, int N) {
       const size_t plain = (size_t)cap_grid(M, 64, 128) * N * sizeof(float);
       return fused > plain ? fused : plain;
     }
-    case PM_WS_UNSHUFFLE_BWD: return (size_t)128 * N * sizeof(float);
+    case PM_WS_UNSHUFFLE_BWD: return (size_t)1024 * N * sizeof(float);  // partial rows of the mask-token gradient
     default: return 0;
   }
 }
