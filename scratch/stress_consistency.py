@@ -27,7 +27,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 import torch
 runs = {"base": {}, "base2": {}, "nosplit": {"PM_SPLIT_FWD": "1"}, "nooverlap": {"PM_OVERLAP_ADAMW": "0"},
         "wgrad256": {"PM_WGRAD_BLOCKS": "256"}, "nogroup": {"PM_GROUP_WGRAD": "0"}, "nosplitk": {"PM_GROUP_SPLIT": "0"},
-        "tail0": {"PM_UNGROUP_TAIL": "0"}, "dgradpp": {"PM_DGRAD_PP": "1"}}
+        "tail0": {"PM_UNGROUP_TAIL": "0"}, "dgradpp": {"PM_DGRAD_PP": "1"}, "noblockcalls": {"PM_BLOCK_CALLS": "0"},
+        # every kernel serialised by the runtime: if the asynchronous multi-stream schedule had a race, this run would differ
+        "serialized": {"AMD_SERIALIZE_KERNEL": "3", "AMD_SERIALIZE_COPY": "3"}}
 out = {}
 for name, env in runs.items():
     path = f"/tmp/stress_{name}.pt"
