@@ -120,6 +120,13 @@ typedef struct pm_wgrad_item {
 int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_dtype, int max_blocks, void* workspace, size_t ws_bytes,
                    void* stream);
 size_t pm_wgrad_group_workspace_bytes(const pm_wgrad_item* items, int n, int K, int in_dtype);
+/* Admission test and plan of pm_wgrad_group WITHOUT launching: returns the status pm_wgrad_group would return for these
+ * shapes / alignments (PM_OK, PM_ESHAPE, PM_EALIGN, PM_EINVAL) and, when PM_OK, the scratch it wants (*ws_bytes), the number
+ * of 256x256 output tiles of the group (*tiles256) and the k-slices per tile (*k_slices; 1 = whole-K tiles, no slabs).  The
+ * pointers of the items are only checked for NULL / alignment.  pm_vit_block_bwd runs this before its first launch; a host
+ * engine uses it instead of restating the rules. */
+int pm_wgrad_group_plan(const pm_wgrad_item* items, int n, int K, int in_dtype, size_t* ws_bytes, int* tiles256,
+                        int* k_slices);
 
 /* pm_gemm followed by the column sums of the stored result: colsum[n] += sum_m C[m][n] (f32 [N]) -- the bias gradient of
  * the Linear whose output gradient C is (reference: autograd of nn.Linear).  Convenience composition (pm_gemm_ws +
@@ -244,9 +251,9 @@ int pm_vit_block_fwd(const pm_block_fwd_desc* d, void* stream);
  * sums of din (bias gradient of the Linear that produced the block input), NULL when there is none; accumulate bit j
  * (0 qkv, 1 proj, 2 fc1, 3 fc2): dW += instead of dW =.  ev_join (optional), ev_fork, ev_done are hipEvent_t of the caller:
  * ev_done fires when this block's matrix gradients are final and its operands may be overwritten.  The library creates,
- * keeps and frees nothing.  Returns the status of the first failing launch (PM_ESHAPE from pm_wgrad_group: the caller falls
- * back to per-kernel calls before anything was enqueued on the side stream -- check shapes with
- * pm_wgrad_group_workspace_bytes / the admission rules first). */
+ * keeps and frees nothing.  The weight-gradient group is validated (pm_wgrad_group_plan: shapes, alignment, workspace size)
+ * BEFORE the first launch: a refusal (PM_ESHAPE / PM_EALIGN / PM_EINVAL) returns with nothing enqueued on either stream, and
+ * the caller falls back to per-kernel calls.  Any later non-zero status is a launch failure (PM_ELAUNCH). */
 typedef struct pm_block_bwd_desc {
   const float* x_in;
   const float* x_mid;

@@ -27,6 +27,7 @@ SIGNATURES = {
     "pm_gemm_ws": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P],
     "pm_gemm_ex": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, I, I, I, P, ctypes.c_size_t, P, P],
     "pm_wgrad_group": [P, I, I, I, I, P, ctypes.c_size_t, P],
+    "pm_wgrad_group_plan": [P, I, I, I, P, P, P],
     "pm_gemm_colsum": [P, L, I, P, L, I, I, P, P, L, I, I, P, P, P, I, I, I, P, ctypes.c_size_t, P],
     "pm_attention_fwd": [P, P, P, I, I, I, I, I, P],
     "pm_attention_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
@@ -55,7 +56,7 @@ SIGNATURES = {
     "pm_grad_stats": [P, L, P, P],
 }
 
-ABI_VERSION = 5  # pm_abi_version() of the library these signatures describe
+ABI_VERSION = 6  # pm_abi_version() of the library these signatures describe
 
 WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4
 

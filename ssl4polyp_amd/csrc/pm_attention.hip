@@ -12,17 +12,23 @@
 // with no LDS round trip ("accumulator as operand"):
 //   fwd   : S^T[key][q] = K Q^T   (lane = q)  -> softmax over registers (+1 cross-half shuffle)
 //           O^T[d][q]  += V^T[d][key] P^T[key][q]          (V^T fragments by ds_read_b64_tr_b16)
-//   bwd_q : S^T, dP^T[key][q] = V dO^T (lane = q) -> dS^T -> dQ^T[d][q] += K^T[d][key] dS^T[key][q]
-//   bwd_kv: S[q][key] = Q K^T, dP[q][key] = dO V^T (lane = key) ->
-//           dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+//   bwd   : bf16: ONE kernel per (batch, head) (attn_bwd_fused_kernel below): Q, K, V, dO staged once by LDS-DMA;
+//           pass 1 (wave = query tile, lane = q):  S^T, dP^T[key][q] = V dO^T -> dS^T -> dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+//           pass 2 (wave = key tile, lane = key):  S[q][key] = Q K^T, dP[q][key] = dO V^T ->
+//                   dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+//           f32 mode keeps the two-kernel form (attn_bwd_q_kernel / attn_bwd_kv_kernel: the same two passes, each staging
+//           half of the head and fetching the other half as per-lane global fragments).
 // Every output tile therefore has (q or key) on the lane and 4 consecutive d per register quad: stores
 // are 8-B (bf16) / 16-B (f32) vectors into the [B,N,(3,)H,dh] activations, the head transpose is free.
-// S and dP are recomputed in both backward kernels (7 products instead of 5) to avoid any cross-wave
-// reduction or atomics.  Roofline: MFMA-bound; algorithmic FLOPs fwd 4*N^2*dh per head, bwd 10*N^2*dh.
+// S and dP are recomputed in pass 2 (7 products instead of 5) to avoid any cross-wave reduction or atomics:
+// deterministic.  Roofline: HBM / MFMA; algorithmic FLOPs fwd 4*N^2*dh per head, bwd 10*N^2*dh.
 #include "pm_common.h"
 #include <stdlib.h>
 
 namespace {
+
+// tile loops of the backward kernels: two tiles per iteration at dh = 32 (half the registers per tile)
+template <int DH> constexpr int kTileUnroll = DH == 32 ? 2 : 1;
 
 template <int RB> __device__ __forceinline__ int swz(int row) {
   // XOR applied to the 16-B chunk index of LDS row `row` (row = RB bytes).  Chosen so that BOTH the
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
     // dh = 32: two key tiles in flight per wave (the loop is a latency chain; registers allow it: 80 VGPRs)
-#pragma unroll (DH == 32 ? 2 : 1)
+#pragma unroll kTileUnroll<DH>
     for (int kt = 0; kt < NT; ++kt) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(cons
       dk[dt] = zero16();
       dv[dt] = zero16();
     }
-#pragma unroll (DH == 32 ? 2 : 1)
+#pragma unroll kTileUnroll<DH>
     for (int qt = 0; qt < NT; ++qt) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* _
     f32x16 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
-#pragma unroll (DH == 32 ? 2 : 1)
+#pragma unroll kTileUnroll<DH>
     for (int kt = 0; kt < ((dbg & 1) ? 0 : NT); ++kt) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* _
       dk[dt] = zero16();
       dv[dt] = zero16();
     }
-#pragma unroll (DH == 32 ? 2 : 1)
+#pragma unroll kTileUnroll<DH>
     for (int qt = 0; qt < ((dbg & 2) ? 0 : NT); ++qt) {
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll

@@ -53,6 +53,22 @@ extern "C" int pm_vit_block_bwd(const pm_block_bwd_desc* d, void* stream) {
   opts.max_blocks = 0;
   opts.variant = d->gemm_variant;
   int st;
+  // the grouped weight gradients are the only launch of this block that can refuse its shapes: plan them BEFORE anything is
+  // enqueued, so that a refusal leaves both streams untouched (the caller then issues the block kernel by kernel)
+  pm_wgrad_item it[4];
+  {
+    const void* dys[4] = {d->dx_act, d->d_hidden, d->dmid_act, d->d_qkv};
+    const void* xs[4] = {d->h_act, d->ln2, d->attn, d->ln1};
+    float* dws[4] = {d->g_fc2_w, d->g_fc1_w, d->g_proj_w, d->g_qkv_w};
+    float* dbs[4] = {nullptr, d->g_fc1_b, nullptr, d->g_qkv_b};
+    const int n_out[4] = {D, Hd, D, 3 * D}, n_in[4] = {Hd, D, D, D};
+    const int acc_bit[4] = {3, 2, 1, 0};  // accumulate bits: 0 qkv, 1 proj, 2 fc1, 3 fc2
+    for (int j = 0; j < 4; ++j) {
+      it[j].dY = dys[j]; it[j].lddy = n_out[j]; it[j].X = xs[j]; it[j].ldx = n_in[j]; it[j].dW = dws[j]; it[j].lddw = n_in[j];
+      it[j].n_out = n_out[j]; it[j].n_in = n_in[j]; it[j].accumulate = (d->accumulate >> acc_bit[j]) & 1; it[j].dbias = dbs[j];
+    }
+    if ((st = pm_wgrad_group_plan(it, 4, M, dt, nullptr, nullptr, nullptr))) return st;
+  }
   if (d->ev_join && hipStreamWaitEvent(main, (hipEvent_t)d->ev_join, 0) != hipSuccess) return PM_ELAUNCH;
   // ---- MLP branch
   if ((st = pm_gemm_ex(d->dx_act, D, 0, d->fc2_w, Hd, 1, dt, nullptr, d->d_hidden, Hd, dt, PM_EPI_DGELU, (void*)d->h_pre, nullptr, M,
@@ -74,17 +90,6 @@ extern "C" int pm_vit_block_bwd(const pm_block_bwd_desc* d, void* stream) {
   // ---- weight gradients of the block: one grouped launch on the side stream, beside the rest of this chain and the next block's
   if (hipEventRecord((hipEvent_t)d->ev_fork, main) != hipSuccess) return PM_ELAUNCH;
   if (hipStreamWaitEvent(side, (hipEvent_t)d->ev_fork, 0) != hipSuccess) return PM_ELAUNCH;
-  pm_wgrad_item it[4];
-  const void* dys[4] = {d->dx_act, d->d_hidden, d->dmid_act, d->d_qkv};
-  const void* xs[4] = {d->h_act, d->ln2, d->attn, d->ln1};
-  float* dws[4] = {d->g_fc2_w, d->g_fc1_w, d->g_proj_w, d->g_qkv_w};
-  float* dbs[4] = {nullptr, d->g_fc1_b, nullptr, d->g_qkv_b};
-  const int n_out[4] = {D, Hd, D, 3 * D}, n_in[4] = {Hd, D, D, D};
-  const int acc_bit[4] = {3, 2, 1, 0};  // accumulate bits: 0 qkv, 1 proj, 2 fc1, 3 fc2
-  for (int j = 0; j < 4; ++j) {
-    it[j].dY = dys[j]; it[j].lddy = n_out[j]; it[j].X = xs[j]; it[j].ldx = n_in[j]; it[j].dW = dws[j]; it[j].lddw = n_in[j];
-    it[j].n_out = n_out[j]; it[j].n_in = n_in[j]; it[j].accumulate = (d->accumulate >> acc_bit[j]) & 1; it[j].dbias = dbs[j];
-  }
   if ((st = pm_wgrad_group(it, 4, M, dt, d->group_blocks, d->ws_group, d->ws_group_bytes, d->side_stream))) return st;
   if (hipEventRecord((hipEvent_t)d->ev_done, side) != hipSuccess) return PM_ELAUNCH;
   // ---- back on the main chain

@@ -1568,6 +1568,20 @@ extern "C" size_t pm_wgrad_group_workspace_bytes(const pm_wgrad_item* items, int
   return pl.status == PM_OK ? pl.ws_bytes : 0;
 }
 
+extern "C" int pm_wgrad_group_plan(const pm_wgrad_item* items, int n, int K, int in_dtype, size_t* ws_bytes, int* tiles256,
+                                   int* k_slices) {
+  const GroupPlan pl = plan_group(items, n, K, in_dtype);
+  if (ws_bytes) *ws_bytes = pl.status == PM_OK ? pl.ws_bytes : 0;
+  if (k_slices) *k_slices = pl.status == PM_OK ? pl.split : 0;
+  if (tiles256) {
+    long t = 0;
+    if (pl.status == PM_OK)
+      for (int i = 0; i < n; ++i) t += (long)((items[i].n_out + 255) / 256) * ((items[i].n_in + 255) / 256);
+    *tiles256 = (int)t;
+  }
+  return pl.status;
+}
+
 extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_dtype, int max_blocks, void* workspace,
                               size_t ws_bytes, void* stream) {
   GroupPlan pl = plan_group(items, n, K, in_dtype);

@@ -407,9 +407,16 @@ __global__ __launch_bounds__(256) void sup_loss_kernel(const float* __restrict__
     }
     return;
   }
+  // A target outside [0, n_class) (e.g. torch's ignore_index = -100, which this path does not implement) must not index
+  // l[] / class_weights[]: the index is clamped for the reads and the launch reports it the only way a kernel can without
+  // a host sync -- loss and every dlogit become NaN, which the training loops stop on (torch.nn.CrossEntropyLoss raises).
+  float bad = 0.f;
   for (int b = tid; b < B; b += 256) {
     const float* l = logits + (long)b * n_class;
-    const int y = (int)targets[b];
+    const long long yt = targets[b];
+    const bool oob = yt < 0 || yt >= n_class;
+    bad += oob ? 1.f : 0.f;
+    const int y = oob ? 0 : (int)yt;
     float m = l[0];
     for (int k = 1; k < n_class; ++k) m = fmaxf(m, l[k]);
     float se = 0.f;
@@ -420,11 +427,13 @@ __global__ __launch_bounds__(256) void sup_loss_kernel(const float* __restrict__
   }
   const float tn = block_sum256(num, s4);
   const float td = block_sum256(den, s4);
-  if (tid == 0) loss[0] = tn / td;
-  const float inv = 1.0f / td;
+  const float poison = block_sum256(bad, s4) > 0.f ? __builtin_nanf("") : 0.f;
+  if (tid == 0) loss[0] = tn / td + poison;
+  const float inv = 1.0f / td + poison;
   for (int b = tid; b < B; b += 256) {
     const float* l = logits + (long)b * n_class;
-    const int y = (int)targets[b];
+    const long long yt = targets[b];
+    const int y = (yt < 0 || yt >= n_class) ? 0 : (int)yt;
     float m = l[0];
     for (int k = 1; k < n_class; ++k) m = fmaxf(m, l[k]);
     float se = 0.f;

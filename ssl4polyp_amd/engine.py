@@ -191,16 +191,28 @@ class Kernels:
         return True
 
     def can_group_wgrad(self, K: int, dims) -> bool:
-        """Same admission test as pm_wgrad_group (bf16, whole 32-token k-steps, long K, tiles of at least 256 x 128)."""
-        if not (self.GROUP_WGRAD and self.precision == "bf16" and K % 32 == 0 and K >= 2048 and
-                all(o >= 256 and i >= 128 and o % 8 == 0 and i % 8 == 0 for o, i in dims)):
+        """Would pm_wgrad_group take these (n_out, n_in) gradients over K tokens, and does the engine want it to?  The
+        admission rules are the LIBRARY's (pm_wgrad_group_plan: bf16, whole 32-token k-steps, K >= 2048, tiles of at least
+        256 x 128, 16-byte alignment) -- asked, not restated here; the policy on top is the engine's."""
+        if not self.GROUP_WGRAD:
             return False
+        key = ("can_group", K, self.act, tuple(dims), self.GROUP_MIN_TILES, self.GROUP_SPLIT)
+        cache = self.__dict__.setdefault("_need_cache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        n = len(dims)
+        arr = (_lib.WgradItem * n)()
+        for j, (o, i) in enumerate(dims):
+            arr[j] = _lib.WgradItem(64, o, 64, i, 64, i, o, i, 0, None)  # (shapes only: the pointers are checked for alignment)
+        tiles, slices = ctypes.c_int(0), ctypes.c_int(0)
+        st = self.lib.pm_wgrad_group_plan(arr, n, K, self.act, None, ctypes.byref(tiles), ctypes.byref(slices))
         # >= 64 tiles of 256x256 (ViT-B block: 108): one full-K tile per workgroup.  Fewer (the 512-wide MAE decoder block:
-        # 48) group as well when K is long enough to cut every tile into >= 2 k-slices of >= 128 k-steps (the library's
-        # plan: 48 tiles x 4 slices); otherwise the gradients keep the per-GEMM split-K path (PM_GROUP_MIN_TILES=0 forces
-        # grouping: whole-K tiles of 256x128).
-        t256 = sum(((o + 255) // 256) * ((i + 255) // 256) for o, i in dims)
-        return t256 >= self.GROUP_MIN_TILES or (self.GROUP_SPLIT and K // 32 >= 256)
+        # 48) group as well when the library's plan cuts every tile into k-slices (48 tiles x 4 slices of >= 128 k-steps);
+        # otherwise the gradients keep the per-GEMM split-K path (PM_GROUP_MIN_TILES=0 forces grouping: whole-K 256x128 tiles).
+        ok = st == 0 and (tiles.value >= self.GROUP_MIN_TILES or (self.GROUP_SPLIT and slices.value > 1))
+        cache[key] = ok
+        return ok
 
     def linear_wgrad(self, dy, x, dW, M, N_out, K_in, accumulate):
         """dW[N_out,K_in] (+)= dy[M,N_out]^T @ x[M,K_in]  (both operands k-major, f32 output)."""

@@ -210,20 +210,27 @@ class FusedAdamW(torch.optim.Optimizer):
         return out
 
     # -- torch.optim.AdamW-compatible (de)serialisation --------------------------------------------
-    def state_dict(self):
+    def state_dict(self, host: bool = False):
+        """torch.optim.AdamW's layout.  host=True: the moments are copied to host memory HERE, on the calling thread's current
+        stream (two D2H copies of the flat ranges, then per-parameter views) -- what a checkpoint writer thread needs: nothing
+        device-side outlives the call and no device clone of the 2 x f32 moments is made."""
         self._rt.wait_updates()
         f = self._rt.flat
         idx = {id(p): i for i, p in enumerate(f.params)} if f is not None else {}
         state, groups, k = {}, [], 0
+        M, V = self._M, self._V
+        if host and M:
+            M = {r: t.detach().cpu() for r, t in M.items()}
+            V = {r: t.detach().cpu() for r, t in V.items()}
         for group in self.param_groups:
             ids = []
             for p in group["params"]:
                 i = idx.get(id(p))
-                if i is not None and self._M:
+                if i is not None and M:
                     r, lo, n = f.region[i], f.offset[i], f.numel[i]
                     state[k] = {"step": torch.tensor(float(group.get("step", 0))),
-                                "exp_avg": self._M[r][lo:lo + n].view(p.shape).clone(),
-                                "exp_avg_sq": self._V[r][lo:lo + n].view(p.shape).clone()}
+                                "exp_avg": M[r][lo:lo + n].view(p.shape).clone(),
+                                "exp_avg_sq": V[r][lo:lo + n].view(p.shape).clone()}
                 ids.append(k)
                 k += 1
             g = {kk: v for kk, v in group.items() if kk != "params"}

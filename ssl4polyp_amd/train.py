@@ -228,18 +228,50 @@ class _RankBatches:
         return (n - self.rank + self.world - 1) // self.world if n > self.rank else 0
 
 
+_RANK_LOADERS: "weakref.WeakKeyDictionary" = None  # base DataLoader -> {(rank, world, max_batches): rank-local DataLoader}
+
+
+def _rank_local_loader(loader, rank: int, world: int, max_batches: Optional[int]):
+    """DataLoader around this rank's batches of `loader` (same dataset, collate, workers, contexts), built once per
+    (loader, rank, world, max_batches) and kept: with persistent_workers the workers survive from one validation pass to the
+    next instead of respawning every epoch."""
+    import weakref
+    from torch.utils.data import DataLoader, RandomSampler
+    global _RANK_LOADERS
+    if _RANK_LOADERS is None:
+        _RANK_LOADERS = weakref.WeakKeyDictionary()
+    per = _RANK_LOADERS.setdefault(loader, {})
+    key = (rank, world, max_batches)
+    hit = per.get(key)
+    if hit is not None:
+        return hit
+    # every rank walks ITS OWN copy of the base batch sampler and keeps batches rank, rank + world, ...: the copies must
+    # produce the same order, i.e. the sampler is sequential or seeded identically on every rank.  An unseeded RandomSampler
+    # would silently duplicate some samples and miss others in the gathered result.
+    inner = getattr(loader.batch_sampler, "sampler", None)
+    if isinstance(inner, RandomSampler) and getattr(inner, "generator", None) is None:
+        raise ValueError("sharded evaluation needs a loader whose order is the same on every rank: the reference validates "
+                         "with shuffle=False (tc.py:6660-6728); got an unseeded RandomSampler")
+    kw = dict(num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
+              worker_init_fn=loader.worker_init_fn, timeout=loader.timeout, generator=loader.generator)
+    if getattr(loader, "pin_memory_device", ""):
+        kw["pin_memory_device"] = loader.pin_memory_device
+    if loader.num_workers > 0:
+        kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=loader.persistent_workers,
+                  multiprocessing_context=loader.multiprocessing_context)
+    mine = DataLoader(loader.dataset, batch_sampler=_RankBatches(loader.batch_sampler, rank, world, max_batches), **kw)
+    per[key] = mine
+    return mine
+
+
 def shard_eval_loader(loader, rank: int, world: int, max_batches: Optional[int] = None):
     """This rank's share of an evaluation loader as (global batch index, batch) pairs.  A torch DataLoader is rebuilt
-    around a rank-local batch sampler, so its workers only open / decode / transform this rank's frames (PackDataset does
-    PIL open + transform per item, data/packs.py:70-80); any other iterable is walked with the foreign batches skipped."""
+    (once, see _rank_local_loader) around a rank-local batch sampler, so its workers only open / decode / transform this
+    rank's frames (PackDataset does PIL open + transform per item, data/packs.py:70-80); any other iterable is walked with
+    the foreign batches skipped."""
     from torch.utils.data import DataLoader
     if isinstance(loader, DataLoader) and loader.batch_sampler is not None:
-        kw = dict(num_workers=loader.num_workers, collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
-                  worker_init_fn=loader.worker_init_fn, timeout=loader.timeout, generator=loader.generator)
-        if loader.num_workers > 0:
-            kw.update(prefetch_factor=loader.prefetch_factor, persistent_workers=False)
-        mine = DataLoader(loader.dataset, batch_sampler=_RankBatches(loader.batch_sampler, rank, world, max_batches), **kw)
-        for j, batch in enumerate(mine):
+        for j, batch in enumerate(_rank_local_loader(loader, rank, world, max_batches)):
             yield rank + j * world, batch
         return
     for it, batch in enumerate(loader):
@@ -252,11 +284,14 @@ def shard_eval_loader(loader, rank: int, world: int, max_batches: Optional[int] 
 @torch.no_grad()
 def evaluate_cls(model, loader: Iterable, device, max_batches: Optional[int] = None, shard: Optional[bool] = None,
                  return_probs: bool = False):
-    """tc.py:4652-4812 forward part: forward-only kernels in eval mode; logits (and optionally on-device probabilities)
-    and targets gathered on the host (metrics stay in the reference's code).
+    """tc.py:4652-4812 forward part: forward-only kernels in eval mode; logits (and optionally probabilities) of the whole
+    pass stay ON THE DEVICE and cross to the host once at the end -- the reference does `logits.detach().cpu()` + `torch.cat`
+    per batch (tc.py:4790-4812), a host sync per batch that drains the queue.  Targets never leave the host.  Metrics stay in
+    the reference's code.
     shard (default: whenever torch.distributed is initialised with world > 1): rank r evaluates batches r, r + world, ...
-    through a rank-local batch sampler (it never decodes another rank's frames); the pieces are all-gathered and returned
-    in loader order on every rank -- the reference validates on rank 0 only while the other GPUs idle (tc.py:6660-6728)."""
+    through a rank-local batch sampler (it never decodes another rank's frames); the pieces are all-gathered (one padded
+    device collective) and returned in loader order on every rank -- the reference validates on rank 0 only while the other
+    GPUs idle (tc.py:6660-6728)."""
     model.eval()
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
@@ -264,20 +299,44 @@ def evaluate_cls(model, loader: Iterable, device, max_batches: Optional[int] = N
         shard = world > 1
     if not shard:
         world, rank = 1, 0
-    mine = []
+    dev = torch.device(device)
+    idx, sizes, lgs, tgs = [], [], [], []
     for it, batch in shard_eval_loader(loader, rank, world, max_batches):
-        lg = model(batch[0].to(device, non_blocking=True)).float()
-        pr = class_probabilities(lg) if return_probs else None
-        mine.append((it, lg.cpu(), batch[1].cpu(), pr.cpu() if pr is not None else None))
+        lg = model(batch[0].to(dev, non_blocking=True)).float()   # stays on the device
+        idx.append(it)
+        sizes.append(lg.shape[0])
+        lgs.append(lg)
+        tgs.append(torch.as_tensor(batch[1]).reshape(-1).to(torch.int64))
+    n_class = lgs[0].shape[1] if lgs else 0
     if world > 1:
-        parts = [None] * world
-        dist.all_gather_object(parts, mine)
-        mine = sorted((x for p in parts for x in p), key=lambda x: x[0])
-    logits = torch.cat([x[1] for x in mine])
-    targets = torch.cat([x[2] for x in mine])
+        # the bookkeeping (batch indices, sizes, host-side targets) is tiny and goes as one object gather; the logits travel
+        # as ONE padded device collective (ranks may hold different row counts: ragged last batch, odd batch count)
+        meta = [None] * world
+        dist.all_gather_object(meta, (idx, sizes, n_class, torch.cat(tgs) if tgs else torch.zeros(0, dtype=torch.int64)))
+        n_class = max(m[2] for m in meta)
+        rows = [sum(m[1]) for m in meta]
+        pad = max(rows) if rows else 0
+        mine = torch.zeros(pad, n_class, dtype=torch.float32, device=dev)
+        if lgs:
+            mine[:rows[rank]] = torch.cat(lgs)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        pieces = []  # (global batch index, logits rows on the device, targets)
+        for r, (r_idx, r_sizes, _, r_tg) in enumerate(meta):
+            o = 0
+            for b, n in zip(r_idx, r_sizes):
+                pieces.append((b, parts[r][o:o + n], r_tg[o:o + n]))
+                o += n
+        pieces.sort(key=lambda x: x[0])
+        logits_dev = torch.cat([x[1] for x in pieces]) if pieces else mine[:0]
+        targets = torch.cat([x[2] for x in pieces]) if pieces else torch.zeros(0, dtype=torch.int64)
+    else:
+        logits_dev = torch.cat(lgs) if lgs else torch.zeros(0, 0, device=dev)
+        targets = torch.cat(tgs) if tgs else torch.zeros(0, dtype=torch.int64)
     if return_probs:
-        return logits, targets, torch.cat([x[3] for x in mine])
-    return logits, targets
+        probs_dev = class_probabilities(logits_dev) if logits_dev.numel() else logits_dev.new_zeros(0)
+        return logits_dev.cpu(), targets, probs_dev.cpu()   # the pass's only device -> host transfers
+    return logits_dev.cpu(), targets
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -300,6 +359,30 @@ def grad_scaler_state() -> dict:
 
 def _host_state_dict(model) -> Dict[str, torch.Tensor]:
     return {k: v.detach().cpu() for k, v in _unwrap(model).state_dict().items()}
+
+
+def _host_optimizer_state(optimizer) -> dict:
+    """Optimizer state with every tensor already in host memory, built on the CALLING thread (its current stream orders the
+    copies after the last update): the checkpoint writer thread must never touch device memory -- its own current stream is
+    the default stream, which nothing orders against a training loop that runs under torch.cuda.stream(...)."""
+    import inspect
+    sd_fn = optimizer.state_dict
+    try:
+        takes_host = "host" in inspect.signature(sd_fn).parameters
+    except (TypeError, ValueError):
+        takes_host = False
+    if takes_host:
+        return sd_fn(host=True)
+
+    def to_host(o):
+        if torch.is_tensor(o):
+            return o.detach().cpu()
+        if isinstance(o, dict):
+            return {k: to_host(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return type(o)(to_host(v) for v in o)
+        return o
+    return to_host(sd_fn())
 
 
 def _symlink_pointer(pointer: Path, target: Path) -> None:
@@ -364,7 +447,7 @@ def save_mae_checkpoint(output_dir, epoch: int, model, optimizer, args, scaler_s
     out = Path(output_dir)
     path = out / f"checkpoint-{epoch}.pth"
     if _is_main():
-        to_save = {"model": _host_state_dict(model), "optimizer": optimizer.state_dict(), "epoch": epoch,
+        to_save = {"model": _host_state_dict(model), "optimizer": _host_optimizer_state(optimizer), "epoch": epoch,
                    "scaler": scaler_state if scaler_state else grad_scaler_state(), "args": args}
         _write(to_save, path, out / "last.pth", writer)
     return path
@@ -414,7 +497,7 @@ def save_cls_checkpoint(path, epoch: int, model, optimizer, scheduler=None, loss
     path = Path(path)
     if _is_main():
         payload = {"epoch": epoch, "model_state_dict": _host_state_dict(model),
-                   "optimizer_state_dict": optimizer.state_dict(), "scaler_state_dict": grad_scaler_state(), "loss": loss,
+                   "optimizer_state_dict": _host_optimizer_state(optimizer), "scaler_state_dict": grad_scaler_state(), "loss": loss,
                    "py_state": random.getstate(), "np_state": np.random.get_state(), "torch_state": torch.get_rng_state()}
         if scheduler is not None:
             payload["scheduler_state_dict"] = scheduler.state_dict()
