@@ -2,6 +2,7 @@
 """bench.py -- training-step throughput of the MI355X hot path on synthetic Hyperkvasir-shaped batches.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cls|mae] [--precision bf16|fp32]
+        (N > 1 without a launcher: this process starts the N ranks itself, one per GPU -- self_launch below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = zero_grad -> forward -> loss -> backward (-> RCCL gradient all-reduce) -> fused AdamW, inputs
@@ -580,14 +581,139 @@ def run_workload(args, workload, batch, device, world, rank, headline):
     return rec
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` without a launcher: the parent starts the N ranks itself
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(n: int) -> int:
+    """The reference spawns its own ranks (train_classification.py:8152-8169: mp.spawn(train, nprocs=world_size)); so does
+    the bench when it is called as plain `python bench.py --gpus N` (no WORLD_SIZE in the environment).  The parent never
+    touches the GPU: it starts N fresh interpreters of this very command line with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set (one rank per GPU, torchrun's environment contract), relays rank 0's JSON line, and returns
+    non-zero if any rank fails.  A rank that dies must not leave the others parked inside an RCCL collective: the first
+    non-zero exit (or the overall time limit, BENCH_LAUNCH_TIMEOUT seconds, default 3000) ends every remaining rank --
+    SIGTERM to exactly the process groups started here, SIGKILL after a 10 s grace."""
+    import signal
+    import socket
+    import tempfile
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    limit = float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "3000"))
+    out0 = tempfile.TemporaryFile(mode="w+")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, start_new_session=True))
+
+    def end_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)  # each rank leads its own session: the group is exactly what was started here
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    t0 = time.monotonic()
+    rc = 0
+    why = ""
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc = bad[0][1] if bad[0][1] > 0 else 1
+                why = f"rank {bad[0][0]} exited with status {bad[0][1]}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() - t0 > limit:
+                rc, why = 124, f"time limit of {limit:.0f} s (BENCH_LAUNCH_TIMEOUT)"
+                break
+            time.sleep(0.1)
+    except KeyboardInterrupt:
+        rc, why = 130, "interrupted"
+    if rc:
+        print(f"[bench] {why}: ending the other ranks", file=sys.stderr, flush=True)
+        end_all(signal.SIGTERM)
+        t1 = time.monotonic()
+        while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 10:
+            time.sleep(0.1)
+        end_all(signal.SIGKILL)
+        for p in procs:
+            p.wait()
+        return rc
+    # stdout of the job = rank 0's ONE JSON line; whatever else a library printed on rank 0's stdout (gloo / RCCL banners)
+    # goes to stderr
+    out0.seek(0)
+    lines = [ln for ln in out0.read().splitlines() if ln.strip()]
+    js = [i for i, ln in enumerate(lines) if ln.lstrip().startswith("{") and ln.rstrip().endswith("}")]
+    for i, ln in enumerate(lines):
+        if not js or i != js[-1]:
+            print(ln, file=sys.stderr)
+    if not js:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    print(lines[js[-1]], flush=True)
+    return 0
+
+
+def run_stub(args, world, rank):
+    """BENCH_STUB=1 (tests/test_bench_launch_cpu.py; no GPU in the build container): the launch, rendezvous, barrier /
+    max-over-ranks timing and rank-0 JSON path of this file with gloo on the CPU and a stand-in step (a small all-reduce).
+    Never a measurement: the line says so in `data`."""
+    if os.environ.get("BENCH_STUB_FAIL_RANK") == str(rank):
+        sys.exit(3)  # a rank that dies before the rendezvous: the launcher must end the others and report failure
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo")
+    x = torch.ones(1 << 12)
+
+    def step():
+        y = x * (rank + 1)
+        if world > 1:
+            dist.all_reduce(y)
+        return y
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(64 * world * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "stub step on the CPU (launch-path test, not a measurement)",
+                          "config": {"workload": "stub", "global_batch": 64 * world, "parallelism": f"dp{world}",
+                                     "allreduce_check": float(y[0])}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))  # before anything touches the GPU in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or unset WORLD_SIZE and let "
+                 "bench.py start the ranks itself)")
+    if os.environ.get("BENCH_STUB") == "1":
+        return run_stub(args, world, rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # rehearsal hook (one-GPU box): BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo, so the N>1 code path

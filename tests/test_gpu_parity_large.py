@@ -258,3 +258,45 @@ def test_pretrain_checkpoint_feeds_finetune_at_vitb_size(tmp_path):
         assert torch.equal(x, y), k
     x = imgs[:4].to(DEV)
     assert torch.equal(a.to(DEV)(x), b.to(DEV)(x))
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", 1e-2)])
+def test_evaluate_cls_vs_oracle_with_ragged_last_batch(prec, tol):
+    """f3, the evaluation forward path (tc.py:4652-4812): `train.evaluate_cls` over a loader whose last batch is ragged
+    (22 frames in batches of 8: 8, 8, 6), ViT-B/16, against oracle.vit_classify on the same weights and frames --
+    logits, sigmoid(l1 - l0) probabilities and the targets in loader order.  fp32 mode: <= 1e-3 (north-star tolerance);
+    bf16 mode: the measured 7.9e-3 of operand rounding through 12 blocks + 25 %."""
+    import ssl4polyp_amd as A
+    from ssl4polyp_amd import train as T
+    from oracle import vit_mae_ref as O
+    sd, *_ = _oracle_cls(16)
+    cfg = O.VIT_BASE
+    imgs, labels, _ = O.generated_batch(cfg, 22, 77)
+    _threads()
+    with torch.no_grad():
+        want = O.vit_classify(sd, imgs, cfg)
+    vm = A.get_MAE_backbone(None, True, 2, False, None, precision=prec)
+    sd_mae = dict(sd)
+    sd_mae["decoder_pos_embed"] = vm.state_dict()["decoder_pos_embed"]
+    vm.load_state_dict(sd_mae)
+    vm.to(DEV)
+    loader = [(imgs[i:i + 8], labels[i:i + 8], {"frame": list(range(i, min(i + 8, 22)))}) for i in range(0, 22, 8)]
+    n_sync = []
+    orig_cpu = torch.Tensor.cpu
+
+    def counting_cpu(self, *a, **k):
+        if self.is_cuda:
+            n_sync.append(tuple(self.shape))
+        return orig_cpu(self, *a, **k)
+
+    torch.Tensor.cpu = counting_cpu
+    try:
+        lg, tg, pr = T.evaluate_cls(vm, loader, torch.device(DEV, 0), return_probs=True)
+    finally:
+        torch.Tensor.cpu = orig_cpu
+    assert lg.shape == (22, 2) and not lg.is_cuda and torch.equal(tg, labels)
+    e_l, e_p = rel(lg, want), rel(pr, torch.sigmoid(want[:, 1] - want[:, 0]))
+    print(f"[parity] evaluate_cls {prec}: logits max-rel {e_l:.3e}, probabilities max-rel {e_p:.3e}; device->host copies: {n_sync}")
+    assert e_l < tol and e_p < tol
+    assert len(n_sync) == 2, n_sync  # logits + probabilities, once per pass (the reference: once per batch)
+    assert not vm.training
