@@ -218,6 +218,95 @@ def test_vitb_mae_vs_oracle_at_bench_dispatch(prec):
     _grad_report(m.named_parameters(), grads, t["grad"], f"mae B={B} {prec}", t.get("vec"))
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_vitb_mae_fwd_bwd_at_grouped_wgrad_dispatch(prec):
+    """B = 64: encoder M = 64 x 50 = 3 200 and decoder M = 64 x 197 = 12 608 are both multiples of the 32-token k-step, so the
+    bf16 backward takes the kernels the MAE bench (B = 256) runs: the encoder blocks' FULL-K grouped weight gradients
+    (108 tiles) and the decoder blocks' K-SLICED grouped weight gradients (48 tiles x 3 slices + the fixed-order reduce
+    launch) -- B = 48 above misses both (9 456 % 32 = 16: split-K fallback).  The admission is asserted, not assumed.
+    fp32 mode has no grouped kernel (bf16-only dispatch): there the test pins the split-K path at the same shapes."""
+    import ssl4polyp_amd as A
+    B = 64
+    sd, imgs, noise, loss_ref, pred_ref, mask_ref, grads = _oracle_mae(B, True)
+    m = A.mae_vit_base_patch16(norm_pix_loss=False, precision=prec)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    loss.backward()
+    rt = m._rt
+    k = rt.k
+    enc_dims = ((768, 3072), (3072, 768), (768, 768), (2304, 768))
+    dec_dims = ((512, 2048), (2048, 512), (512, 512), (1536, 512))
+    if prec == "bf16":
+        import ctypes
+        from ssl4polyp_amd import _lib
+        assert k.can_group_wgrad(B * 50, enc_dims) and k.can_group_wgrad(B * 197, dec_dims)
+
+        def plan(K, dims):
+            arr = (_lib.WgradItem * 4)(*[_lib.WgradItem(64, o, 64, i, 64, i, o, i, 0, None) for o, i in dims])
+            t, sl = ctypes.c_int(0), ctypes.c_int(0)
+            assert k.lib.pm_wgrad_group_plan(arr, 4, K, _lib.PM_BF16, None, ctypes.byref(t), ctypes.byref(sl)) == 0
+            return t.value, sl.value
+        assert plan(B * 50, enc_dims) == (108, 1)           # full-K tiles, no slabs
+        t_d, s_d = plan(B * 197, dec_dims)
+        assert t_d == 48 and s_d >= 2                        # k-sliced: slabs + one reduce launch per block
+        # and the backward really went through the per-block launcher that issues those grouped launches
+        ws_e = [w for key, lst in rt.pool.items() for w in lst if key[:2] == (768, 12) and w.training][0]
+        ws_d = [w for key, lst in rt.pool.items() for w in lst if key[:2] == (512, 8) and w.training][0]
+        assert len(ws_d.__dict__.get("_bwd_descs", {})) == 8, "every decoder block through pm_vit_block_bwd (grouped, k-sliced)"
+        assert len(ws_e.__dict__.get("_bwd_descs", {})) == 12 - k.UNGROUP_TAIL, "encoder blocks 11..1 grouped, the tail block per GEMM"
+    else:
+        assert not k.can_group_wgrad(B * 50, enc_dims) and not k.can_group_wgrad(B * 197, dec_dims)
+    t = TOL[prec]
+    assert torch.equal(mask.cpu(), mask_ref)
+    e_loss, e_pred = rel(loss, loss_ref), rel_l2(pred, pred_ref)
+    print(f"[parity] mae B={B} {prec}: loss rel {e_loss:.3e}, pred rel-L2 {e_pred:.3e}")
+    assert e_loss < t["loss"] and e_pred < t["pred"]
+    _grad_report(m.named_parameters(), grads, t["grad"], f"mae B={B} {prec}", t.get("vec"))
+
+
+def test_vitb_mae_full_batch_gradients_vs_reference_fixture(golden):
+    """C3 AT ITS REAL SIZE, backward included: the HIP full step (B = 256, bf16 -- the benched dispatch: grouped full-K encoder
+    and k-sliced decoder weight gradients over K = 12 800 / 50 432 tokens) against gradients the REFERENCE itself produced
+    for the same PCG64 weights and batch (tests/golden/make_mae_b256_grads.py ran models_mae.mae_vit_base_patch16 in the
+    build container; a B = 256 backward is minutes of CPU, hence a fixture): the loss, the norm of every parameter
+    gradient, whole vector gradients and 32 x 32 corners of weight-matrix gradients."""
+    import ssl4polyp_amd as A
+    import numpy as np
+    from oracle import vit_mae_ref as O
+    fx = golden("vitb_mae_b256_grads.npz")
+    B = int(fx["batch"])
+    cfg = O.VIT_BASE
+    sd = O.generated_state_dict(cfg, int(fx["weight_seed"]), decoder=True, n_class=None)
+    imgs, _, noise = O.generated_batch(cfg, B, int(fx["batch_seed"]))
+    res = {}
+    for prec in ("bf16", "fp32"):
+        m = A.mae_vit_base_patch16(norm_pix_loss=False, precision=prec)
+        m.load_state_dict(sd)
+        m.to(DEV)
+        loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+        loss.backward()
+        assert np.array_equal(mask.sum(1).cpu().numpy().astype(np.int32), fx["mask_rowsum"])
+        assert np.array_equal(mask[:4].cpu().numpy().astype(np.uint8), fx["mask_first_rows"])
+        params = dict(m.named_parameters())
+        e_loss = abs(float(loss) - float(fx["loss"])) / abs(float(fx["loss"]))
+        norms = {n: float(params[n].grad.double().norm()) for n in fx["grad_names"]}
+        e_norm = {n: abs(norms[n] - w) / w for n, w in zip(fx["grad_names"], fx["grad_norms"]) if not n.endswith("attn.qkv.bias")}
+        e_full = {key[2:]: rel_l2(params[key[2:]].grad, fx[key]) for key in fx
+                  if key.startswith("g/") and not key.endswith("attn.qkv.bias")}
+        e_corner = {key[9:]: rel_l2(params[key[9:]].grad.reshape(params[key[9:]].shape[0], -1)[:32, :32], fx[key])
+                    for key in fx if key.startswith("g_corner/")}
+        wn, wf, wc = max(e_norm, key=e_norm.get), max(e_full, key=e_full.get), max(e_corner, key=e_corner.get)
+        print(f"[parity] mae B={B} {prec} vs reference fixture: loss rel {e_loss:.3e}; gradient norms worst {e_norm[wn]:.3e} ({wn}); "
+              f"vector gradients rel-L2 worst {e_full[wf]:.3e} ({wf}); matrix corners rel-L2 worst {e_corner[wc]:.3e} ({wc})")
+        res[prec] = (e_loss, e_norm[wn], e_full[wf], e_corner[wc])
+        del m
+        torch.cuda.empty_cache()
+    # fp32 mode: the north-star tolerance with room to spare; bf16: SURVEY 8-d (loss 1e-3, gradients 1e-2 rel-L2)
+    assert res["fp32"][0] < 1e-5 and max(res["fp32"][1:]) < 1e-3, res["fp32"]
+    assert res["bf16"][0] < 1e-3 and res["bf16"][1] < 1e-2 and res["bf16"][2] < 1e-2 and res["bf16"][3] < 1e-2, res["bf16"]
+
+
 def test_vitb_mae_forward_loss_at_full_batch():
     """The benchmarked MAE configuration itself (C3: B = 256, bf16): forward + loss against the oracle."""
     import ssl4polyp_amd as A
@@ -300,3 +389,59 @@ def test_evaluate_cls_vs_oracle_with_ragged_last_batch(prec, tol):
     assert e_l < tol and e_p < tol
     assert len(n_sync) == 2, n_sync  # logits + probabilities, once per pass (the reference: once per batch)
     assert not vm.training
+
+
+@pytest.mark.parametrize("kind", ["mae", "cls"])
+def test_training_trajectory_bf16_vs_fp32_mode(kind):
+    """50 optimizer steps from ONE seed, once in bf16 (the benchmarked dtype) and once with precision="fp32" (exact-f32
+    MFMA, <= 2e-6 from the oracle): the loss CURVES must stay together.  A single-step tolerance says nothing about drift --
+    a biased rounding point (a truncation instead of round-to-nearest, a dropped accumulate) shows up here as a curve that
+    peels away.  ViT-B/16, B = 64; MAE: 4 rotating batches, AdamW(0.9, 0.95), per-iteration warm-up as engine_pretrain.py:47-48;
+    cls: 4 rotating batches with random labels, AdamW lr 1e-4 (tc.py:4531-4546 step order).
+    Band: |loss_bf16 - loss_fp32| <= 2e-2 * loss_fp32 at every step (measured: see the printed maximum)."""
+    import ssl4polyp_amd as A
+    from ssl4polyp_amd.optim import FusedAdamW, add_weight_decay
+    from ssl4polyp_amd.train import mae_lr
+    dev = torch.device(DEV, 0)
+    B, STEPS = 64, 50
+    g = torch.Generator(device=dev).manual_seed(99)
+    batches = [torch.randn(B, 3, 224, 224, generator=g, device=dev) for _ in range(4)]
+    labels = [(torch.rand(B, generator=g, device=dev) < 0.5).long() for _ in range(4)]
+    noises = [torch.rand(B, 196, generator=g, device=dev) for _ in range(STEPS)]
+
+    def run(prec):
+        torch.manual_seed(7)
+        if kind == "mae":
+            m = A.mae_vit_base_patch16(precision=prec).to(dev)
+            opt = FusedAdamW(m, add_weight_decay(m, 0.05), lr=1.5e-4 * B / 256 * 4, betas=(0.9, 0.95))
+        else:
+            m = A.get_MAE_backbone(None, True, 2, False, None, precision=prec).to(dev)
+            opt = FusedAdamW(m, lr=1e-4, weight_decay=0.05)
+        base = [gr["lr"] for gr in opt.param_groups]
+        curve = []
+        for it in range(STEPS):
+            if kind == "mae":
+                f = mae_lr(it / 10.0, 1.0, 0.0, 2, 40)   # warm-up over the first 20 steps, then cosine
+                for gr, b in zip(opt.param_groups, base):
+                    gr["lr"] = b * f
+            opt.zero_grad(set_to_none=True)
+            if kind == "mae":
+                loss, _, _ = m(batches[it % 4], mask_ratio=0.75, noise=noises[it])
+            else:
+                loss = A.supervised_loss(m(batches[it % 4]), labels[it % 4], pos_weight=1.0)
+            loss.backward()
+            opt.step()
+            curve.append(loss.detach())
+        out = torch.stack(curve).double().cpu()
+        del m, opt
+        torch.cuda.empty_cache()
+        return out
+
+    c16, c32 = run("bf16"), run("fp32")
+    dev_rel = ((c16 - c32).abs() / c32.abs()).tolist()
+    worst = max(range(STEPS), key=lambda i: dev_rel[i])
+    print(f"[trajectory] {kind}: loss fp32 {c32[0]:.5f} -> {c32[-1]:.5f}, bf16 {c16[0]:.5f} -> {c16[-1]:.5f}; "
+          f"max |bf16 - fp32| / fp32 = {dev_rel[worst]:.3e} at step {worst}; last {dev_rel[-1]:.3e}")
+    assert torch.isfinite(c16).all() and torch.isfinite(c32).all()
+    assert c32[-1] < c32[0], "the fp32 run must make progress for the comparison to mean anything"
+    assert dev_rel[worst] <= 2e-2, (worst, dev_rel[worst])
