@@ -33,6 +33,11 @@ sys.path.insert(0, REPO)
 
 # algorithmic GFLOP per image per training step (contractions only, step = 3 x forward)
 GFLOP_PER_IMG = {"cls": 105.38, "mae": 58.16}
+# C5 regimes (BASELINE.md §3 / SURVEY 8-d): forward 35.13 GFLOP/img; a trainable block adds its backward = 2 x its forward
+# (1.454 GMAC = 2.908 GFLOP) -- dgrad + wgrad; linear probe is forward + head only
+FWD_GFLOP_PER_IMG, BLOCK_FWD_GFLOP = 35.13, 2.908
+FINETUNE_GFLOP = {"none": FWD_GFLOP_PER_IMG, "head+1": FWD_GFLOP_PER_IMG + 2 * BLOCK_FWD_GFLOP,
+                  "head+2": FWD_GFLOP_PER_IMG + 4 * BLOCK_FWD_GFLOP, "full": 105.38}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense bf16 MFMA / f32 MFMA
 PEAK_HBM_GBPS = 8000.0                         # MI355X_MICROARCH.md: HBM3E
 # AdamW on the side stream beside the next forward: +0.5..1 % on the fine-tune step (its forward is MFMA-bound), -1.3 % on the
@@ -66,27 +71,36 @@ def parse():
                          "copied and normalised on a side stream each step (PCIe-inclusive rate, DESIGN.md)")
     ap.add_argument("--preheat", type=float, default=1.0,
                     help="seconds of untimed steps before the W warm-up steps (clock / power ramp after process start; 0 = none)")
+    ap.add_argument("--finetune-mode", choices=["none", "head+1", "head+2", "full"], default="full",
+                    help="C5 regime of the cls workload (classification/finetune.py:49-91): linear probe / lin_head + the last 1 or "
+                         "2 blocks / everything.  The default line (full) also carries the other three as `finetune_modes`")
+    ap.add_argument("--no-c5", action="store_true", help="skip the `finetune_modes` sub-records (none / head+1 / head+2 + eval)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step as one hipGraph (auto = off: eager launch keeps up and overlaps the two streams better)")
     return ap.parse_args()
 
 
-def build(workload, precision, device, world, batch):
+def build(workload, precision, device, world, batch, finetune_mode="full"):
     import ssl4polyp_amd as A
     from ssl4polyp_amd.optim import FusedAdamW, add_weight_decay
     from ssl4polyp_amd.parallel import DataParallel
+    from ssl4polyp_amd.train import configure_finetune_parameters
     torch.manual_seed(0)  # identical init on every rank (then broadcast from rank 0 anyway)
     if workload == "cls":
         model = A.get_MAE_backbone(None, True, 2, False, None, precision=precision)
+        # tc.py:5735-5740: configure_finetune_parameters(model, initial_mode) on whatever the factory returned -- "full" makes
+        # EVERY parameter trainable (the sincos pos_embed too), the other modes freeze everything but lin_head (+ tail blocks)
+        configure_finetune_parameters(model, finetune_mode)
     else:
         model = A.mae_vit_base_patch16(norm_pix_loss=False, precision=precision)
     ddp = DataParallel(model, device)
     if workload == "cls":
-        # tc.py:5751-5768: AdamW(lr 1e-3, wd 0.05) over two groups head / backbone (config/base.yaml:1-4)
+        # tc.py:5751-5768: AdamW(lr 1e-3, wd 0.05) over two groups head / backbone (config/base.yaml:1-4), built from ALL
+        # parameters: frozen ones stay in the optimizer and are skipped for want of a gradient
         head = list(model.lin_head.parameters())
         hid = {id(p) for p in head}
         groups = [{"params": head, "name": "head"},
-                  {"params": [p for p in model.parameters() if id(p) not in hid and p.requires_grad], "name": "backbone"}]
+                  {"params": [p for p in model.parameters() if id(p) not in hid], "name": "backbone"}]
         opt = FusedAdamW(model, groups, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.05, overlap_forward=OVERLAP_ADAMW["cls"])
     else:
         # main_pretrain.py:201-218: lr = blr * eff_batch / 256, betas (0.9, 0.95), no decay on 1-D params
@@ -302,7 +316,10 @@ def cpu_baseline(workload, full):
 HARD_GATES = {"fp32_mode_logits_max_rel": 1e-3, "mae_loss_rel": 1e-3, "mae_pred_rel_l2": 1e-2}
 
 
-def parity_block(workload, model, imgs, labels, precision):
+_ORACLE_CACHE = {}  # (weights checksum, batch checksum) -> oracle / emulation results of the cls parity block (C5 sub-records)
+
+
+def parity_block(workload, model, imgs, labels, precision, light=False):
     """The HIP path against the CPU oracle on the BENCHED configuration: the model's own weights and the benched batch go
     through oracle/vit_mae_ref.py (fp32, CPU); errors as the tests define them (max-rel for logits / loss, rel-L2 for pred
     and parameter gradients).  cls: forward + backward at the full batch, beside (i) the CPU emulation of bf16 operand
@@ -340,14 +357,20 @@ def parity_block(workload, model, imgs, labels, precision):
             imgs_c, labels_c = imgs.cpu(), labels.cpu()
 
             def oracle_run(fn):
-                leaves = {n: v.clone().requires_grad_("pos_embed" not in n) for n, v in sd.items()}
+                # every parameter is a leaf: mode "full" trains pos_embed too (finetune.py:52-55); decoder_pos_embed is unused
+                leaves = {n: v.clone().requires_grad_(True) for n, v in sd.items()}
                 z = fn(leaves)
                 z.retain_grad()
                 lo = O.supervised_loss(z.float(), labels_c, 1.0)
                 lo.backward()
                 return z.detach().float(), lo.detach(), z.grad.detach().float(), {n: v.grad for n, v in leaves.items() if v.grad is not None}
 
-            lr, lo, dz_ref, g_ref = oracle_run(lambda p: O.vit_classify(p, imgs_c, cfg))
+            ckey = (float(sd["lin_head.weight"].double().sum()), float(sd["blocks.5.mlp.fc1.weight"].double().sum()),
+                    float(imgs_c.double().sum()), int(labels_c.sum()))
+            cached = _ORACLE_CACHE.get(ckey)
+            if cached is None:
+                cached = _ORACLE_CACHE[ckey] = {"ref": oracle_run(lambda p: O.vit_classify(p, imgs_c, cfg))}
+            lr, lo, dz_ref, g_ref = cached["ref"]
 
             def grad_errors(grads):
                 errs = {n: rel_l2(g, g_ref[n]) for n, g in grads.items()
@@ -381,7 +404,11 @@ def parity_block(workload, model, imgs, labels, precision):
             if precision == "bf16":
                 # (i) what bf16 operand rounding alone costs HERE, forward and backward, no kernel involved
                 from oracle import vit_bf16_grad_sim as S
-                ze, le, dze, ge = oracle_run(lambda p: S.vit_classify(p, imgs_c, cfg))
+                if "emu" not in cached:
+                    cached["emu"] = oracle_run(lambda p: S.vit_classify(p, imgs_c, cfg))
+                ze, le, dze, ge = cached["emu"]
+                if light:  # a C5 regime: the emulation's errors on the parameters THIS mode trains
+                    ge = {n: g for n, g in ge.items() if n in hip_grads}
                 _, m_e, v_e, al_e, orth_e = grad_errors(ge)
                 emu = {"logits_max_rel": rel(ze, lr), "loss_rel": rel(le, lo), "weight_grad_rel_l2_worst": max(m_e.values()),
                        "weight_grad_common_factor_median": med(al_e), "weight_grad_rel_l2_worst_beside_common_factor": max(orth_e.values()),
@@ -390,25 +417,27 @@ def parity_block(workload, model, imgs, labels, precision):
                 out["bf16_emulation"] = {k: float(f"{v:.3e}") for k, v in emu.items()}
                 out["logits_vs_bf16_emulation_max_rel"] = rel(logits.detach(), ze)
 
-                # (ii) PyTorch's own bf16 autocast of the oracle (the reference's AMP path with bf16 in place of fp16)
-                def autocast(p):
-                    with torch.autocast("cpu", dtype=torch.bfloat16):
-                        return O.vit_classify(p, imgs_c, cfg)
-                za, la, _, ga = oracle_run(autocast)
-                _, m_a, v_a, al_a, _ = grad_errors(ga)
-                out["autocast_yardstick"] = {"logits_max_rel": float(f"{rel(za, lr):.3e}"), "loss_rel": float(f"{rel(la, lo):.3e}"),
-                                             "weight_grad_rel_l2_worst": float(f"{max(m_a.values()):.3e}"),
-                                             "vector_grad_rel_l2_worst": float(f"{max(v_a.values()):.3e}"),
-                                             "weight_grad_common_factor_median": float(f"{med(al_a):.4e}")}
-                # (iii) the same kernels in fp32 mode (exact-f32 MFMA) on the same weights and batch: the north-star tolerance
-                m32 = A.get_MAE_backbone(None, True, 2, False, None, precision="fp32")
-                m32.load_state_dict({k: v for k, v in model.state_dict().items()})
-                m32.to(imgs.device)
-                with torch.no_grad():
-                    l32 = m32(imgs)
-                out["fp32_mode_logits_max_rel"] = rel(l32, lr)
-                del m32
-                gates = {"fp32_mode_logits_max_rel": HARD_GATES["fp32_mode_logits_max_rel"],
+                if not light:
+                    # (ii) PyTorch's own bf16 autocast of the oracle (the reference's AMP path with bf16 in place of fp16)
+                    def autocast(p):
+                        with torch.autocast("cpu", dtype=torch.bfloat16):
+                            return O.vit_classify(p, imgs_c, cfg)
+                    za, la, _, ga = oracle_run(autocast)
+                    _, m_a, v_a, al_a, _ = grad_errors(ga)
+                    out["autocast_yardstick"] = {"logits_max_rel": float(f"{rel(za, lr):.3e}"), "loss_rel": float(f"{rel(la, lo):.3e}"),
+                                                 "weight_grad_rel_l2_worst": float(f"{max(m_a.values()):.3e}"),
+                                                 "vector_grad_rel_l2_worst": float(f"{max(v_a.values()):.3e}"),
+                                                 "weight_grad_common_factor_median": float(f"{med(al_a):.4e}")}
+                    # (iii) the same kernels in fp32 mode (exact-f32 MFMA) on the same weights and batch: the north-star tolerance
+                    m32 = A.get_MAE_backbone(None, True, 2, False, None, precision="fp32")
+                    m32.load_state_dict({k: v for k, v in model.state_dict().items()})
+                    m32.to(imgs.device)
+                    with torch.no_grad():
+                        l32 = m32(imgs)
+                    out["fp32_mode_logits_max_rel"] = rel(l32, lr)
+                    del m32
+                    gates["fp32_mode_logits_max_rel"] = HARD_GATES["fp32_mode_logits_max_rel"]
+                gates = {**gates,
                          "logits_max_rel": 1.25 * emu["logits_max_rel"] + 1e-3,
                          "weight_grad_rel_l2_worst": 1.25 * emu["weight_grad_rel_l2_worst"] + 1e-3,
                          "vector_grad_rel_l2_worst": 1.25 * emu["vector_grad_rel_l2_worst"] + 1e-3,
@@ -509,9 +538,10 @@ def torch_baseline(device, batch, steps=10, warmup=3):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def run_workload(args, workload, batch, device, world, rank, headline):
-    """Build, warm up, time exactly args.steps steps (barrier + synchronize on both sides, max over ranks)."""
-    model, ddp, opt = build(workload, args.precision, device, world, batch)
+def run_workload(args, workload, batch, device, world, rank, headline, finetune_mode="full", light=False):
+    """Build, warm up, time exactly args.steps steps (barrier + synchronize on both sides, max over ranks).
+    light: a C5 sub-record -- no kernel statistics, parity against the cached oracle run of the headline, + eval forward."""
+    model, ddp, opt = build(workload, args.precision, device, world, batch, finetune_mode)
     imgs, labels = make_batch(workload, batch, device, rank)
     eager_step = make_step(workload, ddp, opt, imgs, labels, args.lr_every_step)
     use_graph = args.graph == "on"  # auto: eager (measured faster: graph replay serialises the wgrad side stream)
@@ -538,6 +568,8 @@ def run_workload(args, workload, batch, device, world, rank, headline):
     # region on a restored copy of them: its ~10 s of CPU oracle leave the GPU idle, and a timed loop that starts right
     # after an idle phase measures the clock ramp (first steps up to 1.5x slower) instead of the steady state.
     want_parity = rank == 0 and world == 1 and not args.no_parity
+    if light:
+        args = argparse.Namespace(**{**vars(args), "no_kernel_stats": True})
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if want_parity else None
     # Pre-heat: untimed steps of the same step function until args.preheat seconds have passed, so that clocks and power
     # management have settled before the W warm-up steps (a process that starts timing ~0.15 s after its first launch is
@@ -617,14 +649,40 @@ def run_workload(args, workload, batch, device, world, rank, headline):
         model._rt.wait_updates()
         torch.cuda.synchronize()
         model.load_state_dict(init_state)  # back to the initial weights (the optimizer state is not used by the comparison)
-        parity = parity_block(workload, model, imgs, labels, args.precision)
+        parity = parity_block(workload, model, imgs, labels, args.precision, light=light)
+    eval_rec = None
+    if light:
+        # evaluation forward (tc.py:4652-4812 / f3): eval mode, no autograd, forward-only workspace, same resident batch
+        model.eval()
+        with torch.no_grad():
+            for _ in range(5):
+                ddp(imgs)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            te = time.perf_counter()
+            for _ in range(args.steps):
+                ddp(imgs)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            de = time.perf_counter() - te
+        if world > 1:
+            t = torch.tensor([de], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            de = t.item()
+        ev_ips = batch * world * args.steps / de
+        eval_rec = {"value": round(ev_ips, 1), "unit": "images/sec", "ms_per_batch": round(de / args.steps * 1e3, 3),
+                    "roofline_frac": round(ev_ips / world * FWD_GFLOP_PER_IMG / 1e3 / PEAK_TFLOPS[args.precision], 4)}
+        model.train()
     if rank == 0:
         ips = batch * world * args.steps / dt
-        per_gpu_tflops = ips / world * GFLOP_PER_IMG[workload] / 1e3
+        gflop = FINETUNE_GFLOP[finetune_mode] if workload == "cls" else GFLOP_PER_IMG[workload]
+        per_gpu_tflops = ips / world * gflop / 1e3
         peak = PEAK_TFLOPS[args.precision]
         roof = {"bound": "mfma", "achieved": round(per_gpu_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(per_gpu_tflops / peak, 4), "traffic": None,
-                "basis": f"{GFLOP_PER_IMG[workload]} algorithmic GFLOP/img/step x img/s/GPU (BASELINE.md §3)"}
+                "basis": f"{gflop} algorithmic GFLOP/img/step x img/s/GPU (BASELINE.md §3)"}
         if stats is not None:
             ks, hb, at, gt = stats
             dom = max(ks.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])
@@ -648,7 +706,8 @@ def run_workload(args, workload, batch, device, world, rank, headline):
             roof["gemm_share_of_step"] = round(gt / (dt / args.steps), 3)
         rec = {"value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),
                "host_enqueue_ms_per_step": round(t_enq * 1e3, 3), "step_ms": step_ms, "preheat_steps": preheat_steps,
-               "config": {"workload": WORKLOAD_NAME[workload] + f", bs={batch}/GPU, 224^2, AdamW, random init",
+               "config": {"workload": WORKLOAD_NAME[workload] + f", bs={batch}/GPU, 224^2, AdamW, random init"
+                                      + (f", finetune mode {finetune_mode} (finetune.py:49-91)" if workload == "cls" else ""),
                           "global_batch": batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "lr_schedule": ("per-iteration warm-up (engine_pretrain.py:47-48; 40 epochs x 390 it)" if workload == "mae"
@@ -656,6 +715,10 @@ def run_workload(args, workload, batch, device, world, rank, headline):
                "roofline": roof}
         if parity is not None:
             rec["parity"] = parity
+        if eval_rec is not None:
+            rec["eval_forward"] = eval_rec
+        if light:  # trainable bytes the gradient all-reduce would carry in this mode (parallel.GradSync plan)
+            rec["trainable_params"] = int(sum(p.numel() for p in model.parameters() if p.requires_grad))
     del model, ddp, opt, eager_step, step
     torch.cuda.empty_cache()
     return rec
@@ -810,11 +873,17 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
     batch = args.batch or (64 if args.workload == "cls" else 256)
-    head = run_workload(args, args.workload, batch, device, world, rank, True)
+    head = run_workload(args, args.workload, batch, device, world, rank, True, finetune_mode=args.finetune_mode)
     sub = None
     if args.workload == "cls" and not args.no_mae and not args.batch and args.input == "resident":
         # BASELINE.json metric: "(MAE pretrain + cls finetune)": configs[2], same process, same protocol
         sub = run_workload(args, "mae", 256, device, world, rank, False)
+    c5 = None
+    if (args.workload == "cls" and args.finetune_mode == "full" and not args.no_c5 and not args.batch and args.input == "resident"
+            and args.graph != "on"):
+        # configs[4] (C5): the staged fine-tune regimes of finetune.py:49-91 on the same synthetic step, + the eval forward
+        c5 = {m: run_workload(args, "cls", batch, device, world, rank, False, finetune_mode=m, light=True)
+              for m in ("none", "head+1", "head+2")}
 
     if rank == 0:
         out = {
@@ -832,6 +901,9 @@ def main():
         if sub is not None:
             out["mae"] = {"metric": "training-step images/sec/node, ViT-B/16 224^2 (MAE pre-train)", "steps": args.steps,
                           "warmup": args.warmup, **sub}
+        if c5 is not None:
+            out["finetune_modes"] = {m: {k: v for k, v in r.items() if k not in ("host_enqueue_ms_per_step", "preheat_steps")}
+                                     for m, r in c5.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_full)
         if world == 1 and not args.no_torch_baseline and args.precision == "bf16":

@@ -230,8 +230,15 @@ class _EncoderFrontMixin:
         demb = torch.empty(B * keep, D, dtype=k.act_dtype, device=cols.device)
         dcls = f.grad_view("cls_token") if need("cls_token") else None
         dpos = f.grad_view("pos_embed") if learn_pos and need("pos_embed") else None
-        _lib.check(k.lib.pm_assemble_tokens_bwd(_ptr(dx0), _ptr(ids_keep), _ptr(demb), k.act, _ptr(dcls), _ptr(dpos), B,
-                                                keep, D, _stream()), "pm_assemble_tokens_bwd")
+        if dpos is not None and ids_keep is None:
+            # every sample holds every position: d pos_embed = sum_b dx0[b] -- one fixed-order column sum over the batch of
+            # the [B, (L+1) D] view (cls row included) instead of the scatter's float atomics
+            _lib.check(k.lib.pm_assemble_tokens_bwd(_ptr(dx0), None, _ptr(demb), k.act, _ptr(dcls), None, B, keep, D,
+                                                    _stream()), "pm_assemble_tokens_bwd")
+            k.colsum(dx0.view(B, (keep + 1) * D), dpos.view(-1), B, (keep + 1) * D)
+        else:
+            _lib.check(k.lib.pm_assemble_tokens_bwd(_ptr(dx0), _ptr(ids_keep), _ptr(demb), k.act, _ptr(dcls), _ptr(dpos), B,
+                                                    keep, D, _stream()), "pm_assemble_tokens_bwd")
         if need("patch_embed.proj.weight"):
             k.linear_wgrad(demb, cols, f.grad_view("patch_embed.proj.weight").view(D, PE), B * keep, D, PE, accumulate)
         if need("patch_embed.proj.bias"):
@@ -299,7 +306,10 @@ class _VitClsFn(torch.autograd.Function):
         if not accumulate and need("lin_head.weight"):
             f.grad_view("lin_head.weight").zero_()
         trainable = [any(need(f"blocks.{i}.{n}") for n in BLOCK_PARAM_NAMES) for i in range(g.depth)]
-        learn_pos = bool(getattr(mod, "_learned_pos", False))
+        # timm's table is learnable (models.py:28-33); the MAE-derived classifier's is a frozen sincos buffer-like Parameter
+        # (models_mae.py:37) -- until finetune.py:52-55 (mode "full": requires_grad_(True) on EVERY parameter, applied by
+        # tc.py:5740 to whatever the factory returned) makes it trainable too.  Either way: follow the flag.
+        learn_pos = need("pos_embed")
         front = need("cls_token") or need("patch_embed.proj.weight") or need("patch_embed.proj.bias") or \
             (learn_pos and need("pos_embed"))
         below_head = front or any(trainable)
@@ -329,7 +339,9 @@ class _VitClsFn(torch.autograd.Function):
         if ws is not None:
             rt.put_ws(g, ws)
         ctx.saved = None
-        grads = [None if (accumulate or not nd) else f.grad_view(n) for n, nd in zip(names, needs)]
+        # decoder_pos_embed survives in ViT_from_MAE (models.py:171-175) but takes no part in the forward: like autograd in the
+        # reference it gets NO gradient (None, not zeros -- AdamW must skip it, not decay it) even when mode "full" flags it
+        grads = [None if (accumulate or not nd or n == "decoder_pos_embed") else f.grad_view(n) for n, nd in zip(names, needs)]
         return (None, None, None, None, None, *grads)
 
 

@@ -52,6 +52,41 @@ def cls_cosine_lambda(epoch: int, warmup_epochs: int, total_epochs: int) -> floa
 
 
 # ---------------------------------------------------------------------------------------------------
+# fine-tune regimes (classification/finetune.py:49-91, applied by tc.py:5740 and, per stage, tc.py:924-953)
+# ---------------------------------------------------------------------------------------------------
+FINETUNE_MODES = ("none", "head+1", "head+2", "full")
+
+
+def configure_finetune_parameters(model, mode: str) -> None:
+    """finetune.py:49-91 on a model of this package (the reference's own function works on it unchanged -- it only touches
+    `.parameters()`, `.lin_head`, `.head`, `.blocks`, `.frozen`; this restatement serves bench.py and the tests, which cannot
+    import the reference on the GPU box).  "full": EVERY parameter trainable (the sincos pos_embed of the MAE-derived
+    classifier included, see models._VitClsFn.backward); otherwise everything frozen except lin_head (and `.head` when it is
+    a module with parameters) and the last 1 / 2 blocks.  Gradients are cleared; `.frozen` follows the mode."""
+    import torch.nn as nn
+    mode = str(mode).strip().lower()
+    if mode not in FINETUNE_MODES:
+        raise ValueError(f"Unsupported fine-tuning mode '{mode}'. Expected one of {sorted(FINETUNE_MODES)}.")
+    model = _unwrap(model)
+    for p in model.parameters():
+        p.requires_grad_(mode == "full")
+        p.grad = None
+    if mode != "full":
+        heads = [m for m in (getattr(model, "lin_head", None), getattr(model, "head", None)) if isinstance(m, nn.Module)]
+        for h in heads:
+            for p in h.parameters():
+                p.requires_grad_(True)
+        blocks = getattr(model, "blocks", None)
+        tail = {"head+1": 1, "head+2": 2}.get(mode, 0)
+        if tail and blocks is not None and len(blocks) > 0:
+            for blk in list(blocks)[-tail:]:
+                for p in blk.parameters():
+                    p.requires_grad_(True)
+    if hasattr(model, "frozen"):
+        model.frozen = mode == "none"
+
+
+# ---------------------------------------------------------------------------------------------------
 # loss of the fine-tune path (tc.py:3347-3374, 6086-6104)
 # ---------------------------------------------------------------------------------------------------
 def supervised_loss(logits: torch.Tensor, targets: torch.Tensor, pos_weight: Optional[torch.Tensor] = None,

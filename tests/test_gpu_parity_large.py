@@ -445,3 +445,47 @@ def test_training_trajectory_bf16_vs_fp32_mode(kind):
     assert torch.isfinite(c16).all() and torch.isfinite(c32).all()
     assert c32[-1] < c32[0], "the fp32 run must make progress for the comparison to mean anything"
     assert dev_rel[worst] <= 2e-2, (worst, dev_rel[worst])
+
+
+def test_finetune_mode_full_trains_the_positional_table_like_the_reference():
+    """finetune.py:52-55 (mode "full") sets requires_grad_(True) on EVERY parameter and tc.py:5740 applies it to the model the
+    factory returned -- so under the reference's own CLI the MAE-derived classifier's sincos `pos_embed` (frozen at
+    construction, models_mae.py:37) IS trained in a full fine-tune, while `decoder_pos_embed` (left behind by the decoder's
+    deletion, unused) gets no gradient at all.  Same here: pos_embed's gradient equals the oracle's, decoder_pos_embed's is
+    None, and AdamW moves the one and leaves the other untouched."""
+    import ssl4polyp_amd as A
+    from ssl4polyp_amd.optim import FusedAdamW
+    from oracle import vit_mae_ref as O
+    B = 16
+    sd, imgs, labels, logits_ref, _, _ = _oracle_cls(B)
+    cfg = O.VIT_BASE
+    leaves = {n: v.clone().requires_grad_(True) for n, v in sd.items()}
+    O.supervised_loss(O.vit_classify(leaves, imgs, cfg), labels, 1.7).backward()
+    vm = A.get_MAE_backbone(None, True, 2, False, None, precision="fp32")
+    sd_mae = dict(sd)
+    sd_mae["decoder_pos_embed"] = vm.state_dict()["decoder_pos_embed"]
+    vm.load_state_dict(sd_mae)
+    vm.to(DEV)
+    for p in vm.parameters():   # configure_finetune_parameters(model, "full")
+        p.requires_grad_(True)
+    vm.frozen = False
+    opt = FusedAdamW(vm, lr=1e-3, weight_decay=0.05)
+    before = {n: p.detach().clone() for n, p in vm.named_parameters()}
+    logits = vm(imgs.to(DEV))
+    A.supervised_loss(logits, labels.to(DEV), pos_weight=1.7).backward()
+    params = dict(vm.named_parameters())
+    assert rel(logits, logits_ref) < 1e-3
+    assert params["decoder_pos_embed"].grad is None
+    e = rel_l2(params["pos_embed"].grad, leaves["pos_embed"].grad)
+    print(f"[parity] full fine-tune, pos_embed gradient rel-L2 {e:.3e}; cls_token {rel_l2(params['cls_token'].grad, leaves['cls_token'].grad):.3e}")
+    assert e < 1e-3 and rel_l2(params["cls_token"].grad, leaves["cls_token"].grad) < 1e-3
+    g1 = params["pos_embed"].grad.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(params["decoder_pos_embed"].detach(), before["decoder_pos_embed"])   # skipped, not decayed
+    assert not torch.equal(params["pos_embed"].detach(), before["pos_embed"])
+    # the positional gradient is a fixed-order sum: a second backward of the same step gives the same bits
+    opt.zero_grad(set_to_none=True)
+    vm.load_state_dict({n: b for n, b in before.items()}, strict=False)
+    A.supervised_loss(vm(imgs.to(DEV)), labels.to(DEV), pos_weight=1.7).backward()
+    assert torch.equal(params["pos_embed"].grad, g1)
