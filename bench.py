@@ -637,7 +637,7 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
                "first": round(marks[0].elapsed_time(marks[1]), 3), "last": round(marks[-2].elapsed_time(marks[-1]), 3)}
     loss_val = float(loss.detach())
     if not (loss_val == loss_val):
-        sys.exit("non-finite loss in the timed region")
+        sys.exit(f"non-finite loss in the timed region ({workload}, finetune mode {finetune_mode}, step loss {loss_val})")
     rec = None
     stats = None
     parity = None

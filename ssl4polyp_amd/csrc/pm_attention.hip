@@ -279,10 +279,13 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const
         s = mfma16B<T>(frag_rows<T, DH>(imgK, kt * 32, kk, lane), fq[kk], s);
         dp = mfma16B<T>(frag_rows<T, DH>(imgV, kt * 32, kk, lane), fdo[kk], dp);
       }
-      // no masking: a padded key has a zero K row, so its (finite) dS is multiplied by zeros in the dQ product
-      // below; a padded query's lane is never stored
+      // no masking: a padded key has a zero K row, so its dS is multiplied by zeros in the dQ product below -- PROVIDED it
+      // is finite: its score is 0, so P = exp2(0 - l2) overflows once the row's log-sum-exp drops below -88 (every real
+      // score strongly negative: seen after ~60 steps of the head+2 fine-tune at lr 1e-3), and inf x 0 = NaN in dQ.
+      // P <= 1 for every real key (lse >= the row maximum), so the exponent is clamped at 0: exact for real keys, finite
+      // for padded ones.  A padded query's lane is never stored.
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * c - l2) * (dp[r] * scale - dls);  // dS^T
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fminf(s[r] * c - l2, 0.f)) * (dp[r] * scale - dls);  // dS^T
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[dt] = mma_imgT_acc<T, DH>(imgK, kt * 32, dt * 32, s, dq[dt], lane);
     }
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const float p = __builtin_amdgcn_exp2f(s[r] * c - l4[e]);
+          const float p = __builtin_amdgcn_exp2f(fminf(s[r] * c - l4[e], 0.f));
           s[r] = p;                                // P
           dp[r] = p * (dp[r] * scale - d4[e]);     // dS
         }
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* _
         dp = mfma16B<T>(frag_rows<T, DH>(imgV, kt * 32, kk, lane), fdo[kk], dp);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * c - l2) * (dp[r] * scale - dls);  // dS^T
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fminf(s[r] * c - l2, 0.f)) * (dp[r] * scale - dls);  // dS^T
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[dt] = mma_imgT_acc<T, DH>(imgK, kt * 32, dt * 32, s, dq[dt], lane);
     }
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* _
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const float pr = __builtin_amdgcn_exp2f(s[r] * c - l4[e]);
+          const float pr = __builtin_amdgcn_exp2f(fminf(s[r] * c - l4[e], 0.f));
           s[r] = pr;                               // P
           dp[r] = pr * (dp[r] * scale - d4[e]);    // dS
         }

@@ -22,7 +22,19 @@ DEV = "cuda"
 
 TOL = {  # logits max-rel, loss rel, pred rel-L2, grad rel-L2
     "fp32": dict(logits=1e-3, loss=1e-3, pred=1e-2, grad=1e-2),
-    "bf16": dict(logits=2e-2, loss=1e-3, pred=1e-2, grad=1e-2, vec=1e-2),
+    "bf16": dict(logits=2e-2, loss=1e-3, pred=1e-2, grad=1e-2, vec=1e-2),   # MAE: SURVEY 8-d as written
+}
+# bf16 classifier: MEASURED on MI355X (round 3, deterministic kernels) + 25 %, per batch size -- not a multiple of a yardstick.
+# What the numbers are made of (profiles/r3_rounding_cost_cls_b{16,64}.json): the CPU emulation of bf16
+# OPERAND rounding alone (oracle/vit_bf16_grad_sim.py, no kernel) gives logits 4.8e-3 / 5.5e-3, gradients 1.1e-2 / 3.9e-2 at
+# B = 16 / 64; switching off P, dS, the saved GELU pre-activation or every backward rounding moves them by < 20 %.  The
+# gradient error grows with B because every gradient is ~ (common direction) x sum_b dlogit_b, a 16-fold cancelling sum at
+# B = 64 that a coherent 5e-3 logit shift moves by 3-4 % (bench.py reports that factor as `weight_grad_common_factor_median`).
+# The cls LOSS is one scalar drawn from those logit errors: 3.7e-3 at B = 16, 4.8e-4 at B = 64 -- no rounding variant makes it
+# systematically <= 1e-3 (the emulation: 3.9e-3 / 1.6e-5 all-on, 1.3e-3 / 1.0e-3 with P in f32); fp32 mode is at 4e-7.
+TOL_CLS_BF16 = {
+    16: dict(logits=7.6e-3, loss=4.7e-3, grad=1.5e-2, vec=1.5e-2),     # measured 6.07e-3 / 3.72e-3 / 1.19e-2 / 1.20e-2
+    64: dict(logits=1.07e-2, loss=1.0e-3, grad=3.7e-2, vec=3.8e-2),    # measured 8.56e-3 / 4.85e-4 / 2.95e-2 / 3.03e-2
 }
 
 
@@ -145,22 +157,13 @@ def test_vitb_classifier_vs_oracle_at_bench_dispatch(B, prec):
     logits = vm(imgs.to(DEV))
     loss = A.supervised_loss(logits, labels.to(DEV), pos_weight=1.7)
     loss.backward()
-    t = TOL[prec]
+    t = TOL[prec] if prec == "fp32" else TOL_CLS_BF16[B]
     e_logits, e_loss = rel(logits, logits_ref), rel(loss, loss_ref)
     print(f"[parity] cls B={B} {prec}: logits max-rel {e_logits:.3e}, loss rel {e_loss:.3e}")
-    assert e_logits < t["logits"] and e_loss < max(t["loss"], 0.5 * t["logits"])
+    assert e_logits < t["logits"] and e_loss < t["loss"]
     tol_m, tol_v = t["grad"], t.get("vec")
     if prec == "bf16":
-        # With RANDOM labels the per-sample gradients point in unrelated directions, so the batch gradient is a cancelling
-        # sum: the bf16 rounding noise of the B per-sample terms does not cancel with them, and the RELATIVE error of the
-        # sum grows ~sqrt(B) (measured: 1e-2 at B = 16, 3.9e-2 at B = 64 on the last block, whose gradient comes from the
-        # 64 cls rows alone; fp32 mode stays at ~5e-6).  That is a property of bf16 storage, not of a kernel: PyTorch's
-        # own bf16 autocast of the oracle -- no code of this repository involved -- shows 2.0e-2 / 2.2e-2 at B = 64.  The
-        # HIP path rounds at a few more points than autocast does (P and dS before their MFMAs, the saved GELU
-        # pre-activation), so the bound is SURVEY 8-d's 1e-2 or 2.5 x the autocast yardstick, whichever is larger --
-        # the same factor test_bf16_path_vs_bf16_emulating_oracle uses for the logits.
-        yard = _autocast_cls_grad_errors(B)
-        tol_m, tol_v = max(tol_m, 2.5 * yard["matrix"]), max(tol_v, 2.5 * yard["vector"])
+        _autocast_cls_grad_errors(B)  # context only (printed): PyTorch's own bf16 autocast of the oracle; not part of any gate
     _grad_report(vm.named_parameters(), grads, tol_m, f"cls B={B} {prec}", tol_v)
 
 
@@ -398,7 +401,8 @@ def test_training_trajectory_bf16_vs_fp32_mode(kind):
     a biased rounding point (a truncation instead of round-to-nearest, a dropped accumulate) shows up here as a curve that
     peels away.  ViT-B/16, B = 64; MAE: 4 rotating batches, AdamW(0.9, 0.95), per-iteration warm-up as engine_pretrain.py:47-48;
     cls: 4 rotating batches with random labels, AdamW lr 1e-4 (tc.py:4531-4546 step order).
-    Band: |loss_bf16 - loss_fp32| <= 2e-2 * loss_fp32 at every step (measured: see the printed maximum)."""
+    Band: |loss_bf16 - loss_fp32| / loss_fp32 at every step <= 5e-4 (MAE; measured 2.7e-4) / 1.5e-2 (cls; measured 1.1e-2 in
+    the first steps, where the loss of random labels swings, 1.2e-4 at step 50)."""
     import ssl4polyp_amd as A
     from ssl4polyp_amd.optim import FusedAdamW, add_weight_decay
     from ssl4polyp_amd.train import mae_lr
@@ -444,7 +448,8 @@ def test_training_trajectory_bf16_vs_fp32_mode(kind):
           f"max |bf16 - fp32| / fp32 = {dev_rel[worst]:.3e} at step {worst}; last {dev_rel[-1]:.3e}")
     assert torch.isfinite(c16).all() and torch.isfinite(c32).all()
     assert c32[-1] < c32[0], "the fp32 run must make progress for the comparison to mean anything"
-    assert dev_rel[worst] <= 2e-2, (worst, dev_rel[worst])
+    assert dev_rel[worst] <= (5e-4 if kind == "mae" else 1.5e-2), (worst, dev_rel[worst])
+    assert dev_rel[-1] <= 5e-4, dev_rel[-1]
 
 
 def test_finetune_mode_full_trains_the_positional_table_like_the_reference():
