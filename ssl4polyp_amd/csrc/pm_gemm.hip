@@ -202,6 +202,27 @@ __device__ __forceinline__ void mma_kstep(const char* bx, const char* bw, int wm
   }
 }
 
+// The 32x32x16 MFMA of the ring kernels' k-loops.  Diagnostic build -DPM_MFMA16_TIMING (scratch/mfma16_timing.sh): the same
+// operand registers feed TWO v_mfma_f32_16x16x32_bf16 (same FLOPs, same pipe cycles: 2 x 16 = 32) on two quarters of the
+// accumulator -- the results are WRONG (the fragment maps differ), the build only answers "what clock does the chip hold on
+// this k-loop with the other MFMA shape" (MI355X_MICROARCH.md, DVFS give-back item 7).  Never shipped.
+__device__ __forceinline__ void ring_mfma(const Frag16& a, const Frag16& b, f32x16& acc, int kk) {
+#ifdef PM_MFMA16_TIMING
+  f32x4 lo = {acc[8 * kk], acc[8 * kk + 1], acc[8 * kk + 2], acc[8 * kk + 3]};
+  f32x4 hi = {acc[8 * kk + 4], acc[8 * kk + 5], acc[8 * kk + 6], acc[8 * kk + 7]};
+  lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, lo, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, hi, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    acc[8 * kk + e] = lo[e];
+    acc[8 * kk + 4 + e] = hi[e];
+  }
+#else
+  (void)kk;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+#endif
+}
+
 // XCD-aware tile order: the 8 XCDs take blocks round-robin; give each XCD a contiguous run of tiles so
 // that neighbours (same X panel, consecutive W panels) hit the same private L2.  Bijective for any grid.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -673,7 +694,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
       for (int i = 0; i < NTL; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][i].h, fx[kk][j].h, acc[i][j], 0, 0, 0);
+          ring_mfma(fw[kk][i], fx[kk][j], acc[i][j], kk);
     if constexpr (XSUM) {
       if (do_xsum) {
 #pragma unroll
@@ -758,7 +779,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
 #pragma unroll
       for (int m = 0; m < NMF; ++m) {
         const int kk = m / (NTL * MT), i = (m / MT) % NTL, j = m % MT;
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cw[kk][i].h, cx[kk][j].h, acc[i][j], 0, 0, 0);
+        ring_mfma(cw[kk][i], cx[kk][j], acc[i][j], kk);
         __builtin_amdgcn_sched_barrier(0);
         if (m < NR && rd) read_one(t + 1, m, nw, nx);
         if ((m % PER) == 1 && m / PER < G && ld) piece(t + AHEAD, m / PER);

@@ -106,6 +106,9 @@ class _Runtime:
         # optimizer updates still running on the side stream (FusedAdamW(overlap_forward=True)): (region, lo, hi, event)
         # in launch order; the forward waits for a block's range right before it reads the block's weights
         self.pending_updates: List[tuple] = []
+        # parameters of the module that take no part in its forward and therefore never get a gradient, whatever their
+        # requires_grad flag says (ViT_from_MAE keeps the deleted decoder's positional table, models.py:171-175)
+        self.unused: tuple = ()
 
     def wait_updates(self, mat_through: Optional[int] = None, also=()) -> None:
         """Make the current stream (and the streams in `also`) wait for pending optimizer updates: all of them
@@ -189,7 +192,7 @@ def _update_gate(rt: _Runtime, prefix: str):
 def _plan_grads(rt: _Runtime, names: List[str], needs: List[bool]):
     """Decide fresh vs accumulate-in-place for this backward (see flat.py) and prepare the flat ranges."""
     f = rt.flat
-    tr = [n for n, need in zip(names, needs) if need]
+    tr = [n for n, need in zip(names, needs) if need and n not in rt.unused]
     flat_state = [f.grad_is_flat(n) for n in tr]
     if tr and all(flat_state):
         return True
@@ -341,7 +344,7 @@ class _VitClsFn(torch.autograd.Function):
         ctx.saved = None
         # decoder_pos_embed survives in ViT_from_MAE (models.py:171-175) but takes no part in the forward: like autograd in the
         # reference it gets NO gradient (None, not zeros -- AdamW must skip it, not decay it) even when mode "full" flags it
-        grads = [None if (accumulate or not nd or n == "decoder_pos_embed") else f.grad_view(n) for n, nd in zip(names, needs)]
+        grads = [None if (accumulate or not nd or n in rt.unused) else f.grad_view(n) for n, nd in zip(names, needs)]
         return (None, None, None, None, None, *grads)
 
 
@@ -727,6 +730,7 @@ class ViT_from_MAE(_ClassifierBase):
         self._learned_pos = False
         enc = StackGeom(embed_dim, num_heads, depth, int(embed_dim * 4))
         object.__setattr__(self, "_rt", _Runtime(self, precision or _DEFAULT_PRECISION, enc, None))
+        self._rt.unused = ("decoder_pos_embed",)
 
     def load_my_state_dict(self, state_dict):
         own_state = self.state_dict()
