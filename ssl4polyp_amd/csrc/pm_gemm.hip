@@ -60,6 +60,7 @@ struct GemmArgs {
   int ksteps_split;  // k-steps per split
   float* xsum;         // grouped wgrad: xsum[m] += sum_k X(m, k) (= the bias gradient: column sums of dY), or NULL
   int xsum_store;      // xsum[m] = ... instead of += (partial row sums of a k-slice, reduced later)
+  int col_major;       // tile index -> (tm, tn) column by column instead of row by row (grouped wgrad: see wgrad_group_kernel)
 #ifdef PM_GEMM_STAMP
   unsigned long long* stamps;  // diagnostic build only: per-wave cycle sums of the k-loop segments
 #endif
@@ -621,7 +622,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
     }
   };
 #endif
-  const int tm = tile / a.tiles_n, tn = tile % a.tiles_n;
+  const int tm = a.col_major ? tile % a.tiles_m : tile / a.tiles_n, tn = a.col_major ? tile / a.tiles_m : tile % a.tiles_n;
   const int m0 = tm * BM_, n0 = tn * BN_;
   const __bf16* X = reinterpret_cast<const __bf16*>(a.X);
   const __bf16* W = reinterpret_cast<const __bf16*>(a.W);
@@ -1131,7 +1132,7 @@ struct WgradProb {
   float* dW;          // [M][N]
   long lddy, ldx, lddw;
   int M, N;           // out features, in features
-  int tiles_n;
+  int tiles_n, tiles_m;
   int tile_begin;     // first global tile id of this problem
   int accumulate;     // dW += instead of dW =
   float* dbias;       // [M] += column sums of dY (the Linear's bias gradient), or NULL
@@ -1144,6 +1145,7 @@ struct WgradGroupArgs {
   int n, K, total_tiles;
   int split;          // k-slices per tile (1: the tile's workgroup writes dW itself)
   int ksteps_split;
+  int auto_order;     // per-problem tile order: the shorter side fastest (0: row by row, the A/B baseline)
   long total_vec, bias_begin, bias_total;  // reduce launch: float4 items, then bias rows
 };
 
@@ -1165,8 +1167,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroupArgs g) {
     GemmArgs a;
     a.X = pr.dY; a.W = pr.X; a.ldx = pr.lddy; a.ldw = pr.ldx; a.bias = nullptr; a.C = pr.dW; a.ldc = pr.lddw; a.aux = nullptr;
     a.resid = nullptr; a.M = pr.M; a.N = pr.N; a.K = g.K; a.epilogue = pr.accumulate ? PM_EPI_ACCUM : PM_EPI_STORE;
-    a.c_dtype = PM_F32; a.tiles_m = 0; a.tiles_n = pr.tiles_n; a.split_k = 1; a.ksteps_split = 0;
+    a.c_dtype = PM_F32; a.tiles_m = pr.tiles_m; a.tiles_n = pr.tiles_n; a.split_k = 1; a.ksteps_split = 0;
     a.xsum = pr.dbias; a.xsum_store = 0;
+    // Consecutive work items run on one XCD (xcd_remap) at the same pace, so what they share they fetch once into that XCD's
+    // L2: a tile reads a dY panel [K x 256] and an X panel [K x 256] (6.4 MB each at K = 12 608).  Walk the SHORTER side of the
+    // problem fastest, so that a run of ~13 tiles covers a compact rectangle: fc2's gradient is 3 x 12 tiles -- row by row a run
+    // touches 2 + 12 panels, column by column 3 + 5 (PMC before: 557 MB fetched per ViT-B block against 335 MB algorithmic).
+    a.col_major = g.auto_order ? (pr.tiles_m < pr.tiles_n) : 0;
     if (g.split > 1) {  // a k-slice: plain f32 partials into the slab (gemm_v3_tile offsets C by the slice), reduced afterwards
       a.C = pr.slab; a.ldc = pr.N; a.epilogue = PM_EPI_STORE; a.split_k = g.split; a.ksteps_split = g.ksteps_split;
       a.xsum = pr.dbias ? pr.bias_part + (long)slice * pr.M : nullptr; a.xsum_store = 1;
@@ -1402,6 +1409,7 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
   a.split_k = 1;
   a.xsum = nullptr;
   a.xsum_store = 0;
+  a.col_major = 0;
 #ifdef PM_GEMM_STAMP
   a.stamps = g_stamps;
 #endif
@@ -1529,6 +1537,12 @@ extern "C" int pm_gemm(const void* A, long lda, int a_kmajor, const void* B, lon
 
 namespace {
 
+// A/B switch, read once: PM_GROUP_ORDER=0 walks every problem's tiles row by row (round-2 behaviour)
+int group_order_auto() {
+  static const int v = [] { const char* e = getenv("PM_GROUP_ORDER"); return (e && e[0] == '0') ? 0 : 1; }();
+  return v;
+}
+
 // tuning hook, read once: work items (tiles x k-slices) a group with few tiles is cut into (default 224 of the 256 CUs)
 int group_split_target() {
   static const int v = [] { const char* e = getenv("PM_GROUP_SPLIT_TARGET"); return e && e[0] ? atoi(e) : 224; }();
@@ -1614,6 +1628,7 @@ extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_d
   const int bn = pl.bn;
   WgradGroupArgs g;
   g.n = n; g.K = K; g.split = pl.split; g.ksteps_split = pl.ksteps_split;
+  g.auto_order = group_order_auto();
   int total = 0;
   long vec = 0;
   char* ws = reinterpret_cast<char*>(workspace);
@@ -1623,6 +1638,7 @@ extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_d
     p.dY = it.dY; p.X = it.X; p.dW = it.dW; p.lddy = it.lddy; p.ldx = it.ldx; p.lddw = it.lddw;
     p.M = it.n_out; p.N = it.n_in; p.accumulate = it.accumulate ? 1 : 0; p.dbias = it.dbias;
     p.tiles_n = (it.n_in + bn - 1) / bn;
+    p.tiles_m = (it.n_out + 255) / 256;
     p.tile_begin = total;
     total += ((it.n_out + 255) / 256) * p.tiles_n;
     p.slab = nullptr; p.bias_part = nullptr; p.vec_begin = vec;
