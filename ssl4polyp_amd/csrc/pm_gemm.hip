@@ -1370,6 +1370,10 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
 
 namespace {
 
+int tall_m() {  // tuning hook, read once: row count from which a problem counts as "tall" (see gemm_dispatch)
+  static const int v = [] { const char* e = getenv("PM_TALL_M"); return e && e[0] ? atoi(e) : 20000; }();
+  return v;
+}
 bool dgrad_pp() {  // A/B switch, read once: dgrads on the ping-pong loop
   static const bool v = [] { const char* e = getenv("PM_DGRAD_PP"); return e && e[0] == '1'; }();
   return v;
@@ -1438,6 +1442,16 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
         // so it does for every dgrad (W read as stored by ds_read_b64_tr_b16) since those reads stopped waiting for the
         // whole DMA ring (PM_LDS_IMAGE): dfc1 66 -> 61 us, dqkv 51 -> 47, dfc2 101 -> 96, decoder dfc1 118 -> 107
         if ((epilogue == PM_EPI_RESIDUAL && !b_kmajor) || (b_kmajor && !dgrad_pp())) cfg = cfg == 10 ? 26 : 25;
+        // round 3 (scratch/r3_exp1.sh, r3_exp3.sh):
+        //  * the dGELU dgrad (reads the saved pre-activation, writes an act-typed [M, 4D] tensor) goes to the ping-pong loop
+        //    with the LDS-staged epilogue: stand-alone 96.8 vs 95.1 us at ViT-B, 197 vs 220 us at the MAE decoder, and
+        //    +0.6 % cls step rate in-step (whole 128-B row segments per store instead of 16-B pieces at a 6-KB stride)
+        //  * tall problems (MAE decoder: M = 50 432 -> 197 row tiles, 1.5 rounds of the chip): the epilogue is paid 197 x 2
+        //    times and the direct register epilogue's strided 16-B stores cost more than the staging pass: software-pipelined
+        //    loop + staged epilogue (cfg 24) for f32-residual and dgrad outputs (proj 59 vs 66 us, fc2 145 vs 147, dqkv 80 vs
+        //    83, dproj 37.5 vs 38.5), ping-pong + staged (cfg 8) for the act-typed qkv (96 vs 102)
+        if (epilogue == PM_EPI_DGELU && !dgrad_pp()) cfg = 8;
+        else if (M >= tall_m()) cfg = (epilogue == PM_EPI_STORE && !b_kmajor) ? 8 : 24;
       }
     }
     switch (cfg) {
