@@ -174,10 +174,15 @@ def kernel_stats(model, step):
     def ev2():
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
+    EPI = {0: "store", 1: "gelu", 2: "residual", 3: "dgelu", 4: "accum"}
+
     def gemm(A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, **kw):
         e0, e1 = ev2()
         e0.record(); orig["gemm"](A, lda, akm, B, ldb, bkm, bias, C, ldc, epi, M, N, K, **kw); e1.record()
-        rec.append((("tn" if akm else "n") + ("n" if bkm else "t"), M, N, K, e0, e1))
+        # class = operand layout + epilogue: the dispatcher sends each to its own template instantiation (rocprof lists them
+        # as separate kernels), so the "dominant kernel" below is a kernel symbol, not a merge of several
+        lay = ("tn" if akm else "n") + ("n" if bkm else "t")
+        rec.append((lay if akm else f"{lay}_{EPI.get(epi, epi)}", M, N, K, e0, e1))
 
     def wgrad_group(items, K):
         e0, e1 = ev2()
@@ -685,19 +690,26 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
                 "basis": f"{gflop} algorithmic GFLOP/img/step x img/s/GPU (BASELINE.md §3)"}
         if stats is not None:
             ks, hb, at, gt = stats
-            dom = max(ks.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])
-            names = {"nt": "gemm_v3_kernel (forward: X [M,K] x W [N,K]^T)", "nn": "gemm_v3_kernel (dgrad: dY [M,K] x W [K,N])",
+            dom = max(ks.items(), key=lambda kv: kv[1]["launches"] * kv[1]["avg_us"])  # largest share of GPU time, as rocprof ranks
+            names = {"nt_store": "gemm_v3_kernel (forward, act-typed output: qkv, decoder_pred ...)",
+                     "nt_gelu": "gemm_v3_kernel (forward fc1 + GELU)", "nt_residual": "gemm_v3_kernel (forward, f32 residual epilogue: proj / fc2)",
+                     "nn_store": "gemm_v3_kernel (dgrad: dY [M,K] x W [K,N])", "nn_dgelu": "gemm_v3_kernel (dgrad fc2 + dGELU)",
                      "tnn": "gemm_v3_kernel (split-K weight gradient)", "wgrad_group": "wgrad_group_kernel (all dW of a block, full-K tiles)"}
             roof["kernel"] = {"name": names.get(dom[0], dom[0]), "class": dom[0], **dom[1],
                               "frac": round(dom[1]["tflops"] / peak, 4),
-                              "note": "in-step launch times: launches of the two forward chains / of the dgrad and "
-                                      "weight-gradient streams overlap, so each shares the CUs (stand-alone rates: DESIGN.md)"}
+                              "share_of_gemm_time": round(dom[1]["launches"] * dom[1]["avg_us"] * 1e-6 / max(gt, 1e-12), 3),
+                              "note": "the class with the largest summed in-step launch time (HIP events on its own stream); "
+                                      "launches of the forward chains / of the dgrad and weight-gradient streams overlap, so "
+                                      "each shares the CUs (the grouped weight gradients take ~108 of the 256 CUs by design; "
+                                      "stand-alone rates: DESIGN.md)"}
             try:  # PMC traffic of the dominant kernel, from the committed rocprofv3 --pmc passes (profiles/)
                 with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as fh:
                     t = json.load(fh).get(workload, {}).get(dom[0])
                 if t and args.precision == "bf16" and batch == (64 if workload == "cls" else 256):
                     roof["traffic"] = {"MB_per_launch": t["MB_per_launch"], "algorithmic_MB_per_launch": t["algorithmic_MB_per_launch"],
-                                       "source": t["source"]}
+                                       "source": t["source"],
+                                       "measured": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench (committed under "
+                                                   "profiles/; PMC counters cannot be read from inside the process)"}
             except (OSError, ValueError):
                 pass
             roof["gemm_by_layout"] = ks

@@ -210,6 +210,49 @@ int pm_cast(const float* src, void* dst, int dst_dtype, long n, void* stream);
 int pm_preprocess_u8(const unsigned char* src, const unsigned char* flip_flags, float* dst, int B, int H, int W,
                      float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
 
+/* ---- train-time augmentation on the device (classification/data/transforms.py:234-246) ----------------
+ * The reference applies Resize, ColorJitter(0.4, 0.5, 0.25, 0.01), GaussianBlur((25, 25), sigma in [0.001, 2]), two random flips
+ * and RandomRotation(180) per image in PIL / torchvision 0.10 on DataLoader workers.  These entry points do the same work on
+ * uint8 HWC frames [B][H][W][3] resident in HBM, with the arithmetic of the library routines the reference ends up in (Pillow
+ * Resample.c 8bpc, Blend.c, Convert.c rgb2l / rgb2hsv / hsv2rgb, Geometry.c affine_fixed; torchvision's tensor gaussian_blur):
+ * results equal oracle/augment_ref.py bit for bit, which is pinned against Pillow itself.  Random parameters are the caller's. */
+
+/* Resize (Image.resize(BILINEAR), antialiased): horizontal then vertical pass with Pillow's 22-bit fixed-point taps, which the
+ * caller builds as Resample.c precompute_coeffs + normalize_coeffs_8bpc do: bounds_* i32 [out][2] = (first source index, count),
+ * taps_* i32 [out][ksize].  tmp u8 [B][Hs][Wo][3] (needed when both sizes change).  A pass whose size does not change is skipped. */
+int pm_aug_resize_u8(const unsigned char* src, unsigned char* tmp, unsigned char* dst, const int* bounds_x, const int* taps_x,
+                     int ksize_x, const int* bounds_y, const int* taps_y, int ksize_y, int B, int Hs, int Ws, int Ho, int Wo,
+                     void* stream);
+
+/* ColorJitter: per sample, ops in `order` (0 brightness, 1 contrast, 2 saturation, 3 hue; -1 = none): ImageEnhance blends (float32,
+ * truncating / clipping as Blend.c), contrast against int(mean luminance + 0.5) of the image as it stands before that op, hue as
+ * an HSV round trip with H += hue_shift (uint8 wrap-around; hue_shift = uint8(hue_factor * 255)).  lsum: u64 [B] scratch.
+ * Two launches (exact integer luminance sum, then the chain); src and dst may be the same buffer only if order has no contrast. */
+typedef struct pm_aug_jitter {
+  int order[4];
+  float brightness, contrast, saturation;
+  int hue_shift;
+} pm_aug_jitter;
+int pm_aug_color_jitter_u8(const unsigned char* src, unsigned char* dst, const pm_aug_jitter* jitter, unsigned long long* lsum,
+                           int B, int H, int W, void* stream);
+
+/* GaussianBlur: separable ksize-tap convolution with reflect padding in f32 (taps f32 [B][ksize], one row per sample: the
+ * caller evaluates torchvision's _get_gaussian_kernel1d for its sigma), taps summed in index order with separate multiply and
+ * add, rint + clamp back to u8.  tmp f32 [B][H][W][3].  ksize odd, ksize / 2 < min(H, W). */
+int pm_aug_gaussian_blur_u8(const unsigned char* src, float* tmp, unsigned char* dst, const float* taps, int ksize, int B, int H,
+                            int W, void* stream);
+
+/* Flips, then rotation (Image.rotate(angle, NEAREST, expand=False, fillcolor=0)), then either the rotated u8 frame (to_f32 = 0,
+ * dst u8 [B][H][W][3]) or ToTensor + Normalize (to_f32 = 1, dst f32 [B][3][H][W], as pm_preprocess_u8).  Per sample:
+ * mode 0 = Pillow's 16.16 fixed-point inverse map, xin = (a2 + a0 x + a1 y) >> 16, yin = (a5 + a3 x + a4 y) >> 16 (coefficients
+ * built by the caller as Image.rotate + affine_fixed do); 1 = no rotation; 2 / 3 / 4 = 180 / 90 / 270 degrees (Image.rotate's
+ * transpose fast paths; 90 / 270 need H == W).  flips: bit 0 horizontal, bit 1 vertical, applied BEFORE the rotation. */
+typedef struct pm_aug_geom {
+  int mode, a0, a1, a2, a3, a4, a5, flips;
+} pm_aug_geom;
+int pm_aug_geometry_u8(const unsigned char* src, const pm_aug_geom* geom, void* dst, int to_f32, int B, int H, int W, float mean_r,
+                       float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
+
 /* One transformer block forward for one range of samples in ONE call (timm Block: models_mae.py:39-41,53-55,166-167,
  * 186-187; models.py:122-123,204-205):  x_mid = x + proj(attn(LN1 x));  x_out = x_mid + fc2(gelu(fc1(LN2 x_mid))).
  * Host-side composition of pm_layernorm_fwd / pm_gemm_ex / pm_attention_fwd on `stream`, launch for launch what a caller

@@ -1,0 +1,286 @@
+"""CPU oracle for the device-side AUGMENTATION stages of the input pipeline (TEST INFRASTRUCTURE ONLY, see oracle/__init__.py).
+
+Restates, on uint8 HWC frames, what the reference's train transform does to a PIL image before ToTensor
+(classification/data/transforms.py:234-246):
+    T.Resize((224, 224)); T.ColorJitter(brightness=0.4, contrast=0.5, saturation=0.25, hue=0.01);
+    T.GaussianBlur((25, 25), sigma=(0.001, 2.0)); T.RandomHorizontalFlip(); T.RandomVerticalFlip(); T.RandomRotation(180)
+torchvision 0.10 (absent here) runs these on PIL images through thin wrappers around Pillow (present here: the pin):
+    Resize          -> img.resize((w, h), Image.BILINEAR)                     Pillow src/libImaging/Resample.c (8bpc path)
+    adjust_brightness / contrast / saturation -> ImageEnhance.{Brightness, Contrast, Color}(img).enhance(f) = Image.blend
+                                                                              Pillow src/libImaging/Blend.c, Convert.c (rgb2l)
+    adjust_hue      -> img.convert("HSV"), h += uint8(f * 255) (wraps), convert("RGB")   Convert.c rgb2hsv / hsv2rgb
+    rotate          -> img.rotate(angle, Image.NEAREST, expand=False, center=None, fillcolor=0)   Geometry.c affine_fixed
+    gaussian_blur   -> tensor path of torchvision (functional_tensor.gaussian_blur): float32 conv2d with the outer product of
+                       two 1-D gaussians, reflect padding, torch.round back to uint8   (NOT Pillow: restated, unpinned)
+PINNED against Pillow 12.2 run in the build container (tests/golden/make_augment_fixtures.py -> tests/golden/augment.npz):
+resize, brightness, contrast, saturation, hue, rotation -- bit for bit.  UNPINNED: the gaussian blur (torchvision absent; the
+summation order of its conv2d is not reproducible anyway: this file fixes a separable f32 order and says so) and the RANDOM
+DRAWS of the transforms (torch RNG consumption order of torchvision 0.10, restated in `draw_train_params`).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+PRECISION_BITS = 32 - 8 - 2   # Resample.c
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Resize: Pillow ImagingResample, bilinear (triangle) filter with antialiasing, 8 bits per channel
+# ---------------------------------------------------------------------------------------------------------------------
+def _resample_coeffs(in_size: int, out_size: int):
+    """Resample.c precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter (support 1.0) over the whole input."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int64)
+    kk = np.zeros((out_size, ksize), dtype=np.float64)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        ww = 0.0
+        ss = 1.0 / filterscale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        for x in range(xmax):
+            a = (x + xmin - center + 0.5) * ss
+            w = 1.0 - abs(a) if abs(a) < 1.0 else 0.0
+            kk[xx, x] = w
+            ww += w
+        for x in range(xmax):
+            if ww != 0.0:
+                kk[xx, x] /= ww
+        bounds[xx] = (xmin, xmax)
+    # normalize_coeffs_8bpc: fixed point, round half away from zero
+    ik = np.where(kk < 0, (-0.5 + kk * (1 << PRECISION_BITS)).astype(np.int64), (0.5 + kk * (1 << PRECISION_BITS)).astype(np.int64))
+    return bounds, ik.astype(np.int64), ksize
+
+
+def _clip8(ss: np.ndarray) -> np.ndarray:
+    return np.clip(ss >> PRECISION_BITS, 0, 255).astype(np.uint8)
+
+
+def resize_bilinear(frames: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """uint8 [B, H, W, C] -> uint8 [B, out_h, out_w, C]: horizontal pass, then vertical pass, each rounded to uint8
+    (ImagingResampleInner: a pass is skipped when the size does not change)."""
+    x = frames
+    B, H, W, C = x.shape
+    if out_w != W:
+        bounds, ik, _ = _resample_coeffs(W, out_w)
+        out = np.empty((B, H, out_w, C), dtype=np.uint8)
+        xi = x.astype(np.int64)
+        for xx in range(out_w):
+            xmin, n = bounds[xx]
+            ss = (1 << (PRECISION_BITS - 1)) + np.tensordot(xi[:, :, xmin:xmin + n, :], ik[xx, :n], axes=([2], [0]))
+            out[:, :, xx, :] = _clip8(ss)
+        x = out
+    if out_h != H:
+        bounds, ik, _ = _resample_coeffs(H, out_h)
+        out = np.empty((B, out_h, x.shape[2], C), dtype=np.uint8)
+        xi = x.astype(np.int64)
+        for yy in range(out_h):
+            ymin, n = bounds[yy]
+            ss = (1 << (PRECISION_BITS - 1)) + np.tensordot(xi[:, ymin:ymin + n, :, :], ik[yy, :n], axes=([1], [0]))
+            out[:, yy, :, :] = _clip8(ss)
+        x = out
+    return x
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ColorJitter pieces
+# ---------------------------------------------------------------------------------------------------------------------
+def rgb_to_l(x: np.ndarray) -> np.ndarray:
+    """Convert.c rgb2l: L = (R*19595 + G*38470 + B*7471 + 0x8000) >> 16."""
+    xi = x.astype(np.int64)
+    return ((xi[..., 0] * 19595 + xi[..., 1] * 38470 + xi[..., 2] * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def blend(degenerate: np.ndarray, img: np.ndarray, factor: float) -> np.ndarray:
+    """Blend.c ImagingBlend(degenerate, img, alpha): float32 arithmetic; interpolation truncates, extrapolation clips first."""
+    a = np.float32(factor)
+    d, i = degenerate.astype(np.float32), img.astype(np.float32)
+    t = d + a * (i - d)          # (float) in1 + alpha * ((float) in2 - (float) in1)
+    if 0.0 <= factor <= 1.0:
+        return t.astype(np.uint8)  # (UINT8) cast: truncation
+    return np.where(t <= 0.0, 0, np.where(t >= 255.0, 255, t.astype(np.int64))).astype(np.uint8)
+
+
+def adjust_brightness(img: np.ndarray, f: float) -> np.ndarray:
+    return blend(np.zeros_like(img), img, f)
+
+
+def adjust_contrast(img: np.ndarray, f: float) -> np.ndarray:
+    """ImageEnhance.Contrast: the degenerate image is a flat grey at int(mean(L) + 0.5), per image."""
+    out = np.empty_like(img)
+    for b in range(img.shape[0]):
+        l = rgb_to_l(img[b])
+        mean = int(l.astype(np.float64).sum() / l.size + 0.5)   # ImageStat.Stat(...).mean[0]: sum / count in Python floats
+        out[b] = blend(np.full_like(img[b], mean), img[b], f)
+    return out
+
+
+def adjust_saturation(img: np.ndarray, f: float) -> np.ndarray:
+    l = rgb_to_l(img)
+    return blend(np.repeat(l[..., None], 3, axis=-1), img, f)
+
+
+def rgb_to_hsv(x: np.ndarray) -> np.ndarray:
+    """Convert.c rgb2hsv_row (uint8 in, uint8 out).  The C source mixes `float` variables with double literals, so the
+    promotions matter: s, rc, gc, bc are float32 quotients; `2.0 + rc - bc`, `h / 6.0 + 1.0`, fmod and the `* 255.0` run in
+    double and are rounded to float32 where they are assigned to `float h`."""
+    r, g, b = (x[..., i].astype(np.int64) for i in range(3))
+    maxc = np.maximum(np.maximum(r, g), b)
+    minc = np.minimum(np.minimum(r, g), b)
+    cr = (maxc - minc).astype(np.float32)
+    safe = np.where(cr == 0, np.float32(1), cr)
+    sat = (cr / np.where(maxc == 0, 1, maxc).astype(np.float32)).astype(np.float32)
+    rc = ((maxc - r).astype(np.float32) / safe).astype(np.float32)
+    gc = ((maxc - g).astype(np.float32) / safe).astype(np.float32)
+    bc = ((maxc - b).astype(np.float32) / safe).astype(np.float32)
+    h_r = (bc - gc).astype(np.float32)                                                    # float - float
+    h_g = (2.0 + rc.astype(np.float64) - bc.astype(np.float64)).astype(np.float32)        # double, stored to float
+    h_b = (4.0 + gc.astype(np.float64) - rc.astype(np.float64)).astype(np.float32)
+    h = np.where(r == maxc, h_r, np.where(g == maxc, h_g, h_b)).astype(np.float32)
+    h = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)               # incorrect hue happens if h/6 is negative
+    uh = np.clip((h.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    us = np.clip((sat.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    grey = maxc == minc
+    out = np.stack([np.where(grey, 0, uh), np.where(grey, 0, us), maxc], axis=-1)
+    return out.astype(np.uint8)
+
+
+def hsv_to_rgb(x: np.ndarray) -> np.ndarray:
+    """Convert.c hsv2rgb (float32 intermediates, round-half-up via (int)(v + 0.5) of CLIP8)."""
+    h, s, v = x[..., 0], x[..., 1], x[..., 2]
+    fh = (h.astype(np.float32) * np.float32(6.0) / np.float32(255.0)).astype(np.float32)
+    i = np.floor(fh).astype(np.int64)
+    f = (fh - i.astype(np.float32)).astype(np.float32)
+    fs = (s.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    fv = v.astype(np.float32)
+
+    def rnd(t):  # CLIP8(round(t)): Convert.c uses (UINT8) round()
+        return np.clip(np.floor(t.astype(np.float64) + 0.5), 0, 255).astype(np.int64)
+    p = rnd(fv * (np.float32(1.0) - fs))
+    q = rnd(fv * (np.float32(1.0) - fs * f))
+    t = rnd(fv * (np.float32(1.0) - fs * (np.float32(1.0) - f)))
+    vv = v.astype(np.int64)
+    i6 = i % 6
+    r = np.choose(i6, [vv, q, p, p, t, vv])
+    g = np.choose(i6, [t, vv, vv, q, p, p])
+    b = np.choose(i6, [p, p, t, vv, vv, q])
+    grey = s == 0
+    out = np.stack([np.where(grey, vv, r), np.where(grey, vv, g), np.where(grey, vv, b)], axis=-1)
+    return out.astype(np.uint8)
+
+
+def adjust_hue(img: np.ndarray, f: float) -> np.ndarray:
+    """functional_pil.adjust_hue: H channel += uint8(f * 255) with uint8 wrap-around."""
+    hsv = rgb_to_hsv(img)
+    with np.errstate(over="ignore"):
+        hsv[..., 0] = (hsv[..., 0].astype(np.int64) + int(np.uint8(np.int64(f * 255) & 0xFF))).astype(np.uint8)  # np.uint8(f*255): C cast, wraps
+    return hsv_to_rgb(hsv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Rotation: Pillow Image.rotate -> transform(AFFINE, NEAREST) -> Geometry.c affine_fixed (16.16 fixed point)
+# ---------------------------------------------------------------------------------------------------------------------
+def rotate_matrix(angle_deg: float, w: int, h: int):
+    """Image.rotate: the inverse map (output pixel -> input position) about the image centre, rounded to 15 decimals."""
+    angle = angle_deg % 360.0
+    rad = -math.radians(angle)
+    m = [round(math.cos(rad), 15), round(math.sin(rad), 15), 0.0, round(-math.sin(rad), 15), round(math.cos(rad), 15), 0.0]
+    cx, cy = w / 2.0, h / 2.0
+
+    def tr(x, y):
+        a, b, c, d, e, f = m
+        return a * x + b * y + c, d * x + e * y + f
+    m[2], m[5] = tr(-cx, -cy)
+    m[2] += cx
+    m[5] += cy
+    return m
+
+
+def rotate_nearest(img: np.ndarray, angle_deg: float, fill: int = 0) -> np.ndarray:
+    """uint8 [B, H, W, C]; every sample by the same angle (callers loop for per-sample angles)."""
+    B, H, W, C = img.shape
+    ang = angle_deg % 360.0
+    if ang == 0:
+        return img.copy()
+    if ang == 180:
+        return img[:, ::-1, ::-1].copy()      # Image.rotate fast paths: transpose(ROTATE_180)
+    if ang in (90, 270) and H == W:
+        return np.rot90(img, k=1 if ang == 90 else 3, axes=(1, 2)).copy()
+    a = rotate_matrix(angle_deg, W, H)
+
+    def fix(v):
+        return int(math.floor(v * 65536.0 + 0.5))
+    a0, a1, a3, a4 = fix(a[0]), fix(a[1]), fix(a[3]), fix(a[4])
+    a2 = fix(a[2] + a[0] * 0.5 + a[1] * 0.5)
+    a5 = fix(a[5] + a[3] * 0.5 + a[4] * 0.5)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.int64)
+    xx = a2 + a0 * xs + a1 * ys
+    yy = a5 + a3 * xs + a4 * ys
+    xin, yin = xx >> 16, yy >> 16                     # floor division of the 16.16 value
+    ok = (xin >= 0) & (xin < W) & (yin >= 0) & (yin < H)
+    out = np.full_like(img, fill)
+    out[:, ok] = img[:, yin[ok], xin[ok]]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Gaussian blur (torchvision tensor path, restated: UNPINNED)
+# ---------------------------------------------------------------------------------------------------------------------
+def gaussian_kernel1d(ksize: int, sigma: float) -> np.ndarray:
+    """functional_tensor._get_gaussian_kernel1d, float32."""
+    half = (ksize - 1) * 0.5
+    x = np.linspace(-half, half, ksize, dtype=np.float32)
+    pdf = np.exp(np.float32(-0.5) * (x / np.float32(sigma)) ** 2).astype(np.float32)
+    return (pdf / pdf.sum(dtype=np.float32)).astype(np.float32)
+
+
+def gaussian_blur(img: np.ndarray, ksize: int, sigma: float) -> np.ndarray:
+    """uint8 [B, H, W, C] -> uint8: reflect padding, SEPARABLE float32 convolution (rows first, then columns, taps summed left to
+    right / top to bottom), round half to even (torch.round), cast.  torchvision convolves with the 2-D outer-product kernel in
+    one conv2d whose summation order is an implementation detail: the two agree to <= 1 grey level (tested)."""
+    k = gaussian_kernel1d(ksize, sigma)
+    r = ksize // 2
+    x = img.astype(np.float32)
+    xp = np.pad(x, ((0, 0), (0, 0), (r, r), (0, 0)), mode="reflect")
+    acc = np.zeros_like(x)
+    for t in range(ksize):
+        acc = (acc + k[t] * xp[:, :, t:t + x.shape[2], :]).astype(np.float32)
+    yp = np.pad(acc, ((0, 0), (r, r), (0, 0), (0, 0)), mode="reflect")
+    out = np.zeros_like(x)
+    for t in range(ksize):
+        out = (out + k[t] * yp[:, t:t + x.shape[1], :, :]).astype(np.float32)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole train-time chain on a batch, with explicit parameters
+# ---------------------------------------------------------------------------------------------------------------------
+def train_augment(frames: np.ndarray, params: dict) -> np.ndarray:
+    """frames uint8 [B, H, W, 3] already at the target size; params (all per sample, length B):
+    order [B, 4] (permutation of 0 brightness, 1 contrast, 2 saturation, 3 hue), brightness / contrast / saturation / hue
+    factors, sigma, hflip, vflip (0/1), angle (degrees).  transforms.py:238-245 order: jitter, blur, flips, rotation."""
+    out = np.empty_like(frames)
+    fns = [adjust_brightness, adjust_contrast, adjust_saturation, adjust_hue]
+    names = ["brightness", "contrast", "saturation", "hue"]
+    for b in range(frames.shape[0]):
+        x = frames[b:b + 1]
+        for op in params["order"][b]:
+            x = fns[int(op)](x, float(params[names[int(op)]][b]))
+        x = gaussian_blur(x, 25, float(params["sigma"][b]))
+        if params["hflip"][b]:
+            x = x[:, :, ::-1]
+        if params["vflip"][b]:
+            x = x[:, ::-1]
+        x = rotate_nearest(np.ascontiguousarray(x), float(params["angle"][b]))
+        out[b] = x[0]
+    return out

@@ -1,0 +1,356 @@
+// pm_augment.hip -- the train-time augmentation of the reference's input pipeline on the device, on uint8 HWC frames
+// (classification/data/transforms.py:234-246: Resize, ColorJitter, GaussianBlur((25,25)), flips, RandomRotation(180), then
+// ToTensor + Normalize; the reference runs them per image in PIL / torchvision 0.10 on DataLoader workers).
+// Each kernel restates the arithmetic of the library routine the reference ends up in -- Pillow's Resample.c (8bpc), Blend.c,
+// Convert.c (rgb2l, rgb2hsv, hsv2rgb), Geometry.c (affine_fixed) and torchvision's tensor gaussian_blur -- integer for integer
+// and float for float, so that the results equal oracle/augment_ref.py bit for bit (and through it Pillow 12.2, which pins the
+// oracle in the build container; the blur is the one unpinned stage).  All kernels are HBM-bound byte movers: one pass over a
+// 9.6 MB uint8 batch each (the blur two passes with an f32 intermediate), no LDS, coalesced along the 672-byte pixel rows.
+// Random parameters are drawn on the host (data.py) and arrive as small per-sample arrays.
+#include "pm_common.h"
+
+// The library routines restated here are plain C compiled WITHOUT fused multiply-add (x86-64 baseline), and numpy does not fuse
+// either: every `a * b + c` below must round twice.  hipcc contracts by default (-ffp-contract=fast, which ignores the pragma
+// below; HIP's __fmul_rn / __fadd_rn are plain operators that contract like any other), so this translation unit is compiled
+// with -ffp-contract=off (__graft_entry__.SOURCE_FLAGS) -- the pragma documents the requirement for other build recipes.
+#pragma clang fp contract(off)
+
+namespace {
+
+inline int aug_grid(long work, int cap = 8192) {
+  long g = (work + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resize: Pillow ImagingResampleHorizontal_8bpc / Vertical_8bpc (fixed-point taps built on the host as precompute_coeffs does)
+// ---------------------------------------------------------------------------------------------
+constexpr int kPrecisionBits = 32 - 8 - 2;
+
+// out[b][y][xx][c] = clip8((1 << 21) + sum_t src[b][y][xmin + t][c] * k[xx][t]) >> 22)      (axis = 1: along rows instead)
+__global__ __launch_bounds__(256) void resample_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                       const int* __restrict__ bounds, const int* __restrict__ taps, int ksize,
+                                                       int B, int Hs, int Ws, int Ho, int Wo, int vertical) {
+  const long total = (long)B * Ho * Wo;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int xo = id % Wo;
+    const int yo = (id / Wo) % Ho;
+    const int b = id / ((long)Wo * Ho);
+    const int o = vertical ? yo : xo;
+    const int lo = bounds[2 * o], n = bounds[2 * o + 1];
+    const int* k = taps + (long)o * ksize;
+    int ss0 = 1 << (kPrecisionBits - 1), ss1 = ss0, ss2 = ss0;
+    const unsigned char* p = vertical ? src + (((long)b * Hs + lo) * Ws + xo) * 3 : src + (((long)b * Hs + yo) * Ws + lo) * 3;
+    const long step = vertical ? (long)Ws * 3 : 3;
+    for (int t = 0; t < n; ++t) {
+      const int kk = k[t];
+      ss0 += p[0] * kk;
+      ss1 += p[1] * kk;
+      ss2 += p[2] * kk;
+      p += step;
+    }
+    unsigned char* q = dst + (((long)b * Ho + yo) * Wo + xo) * 3;
+    ss0 >>= kPrecisionBits; ss1 >>= kPrecisionBits; ss2 >>= kPrecisionBits;
+    q[0] = (unsigned char)(ss0 < 0 ? 0 : (ss0 > 255 ? 255 : ss0));
+    q[1] = (unsigned char)(ss1 < 0 ? 0 : (ss1 > 255 ? 255 : ss1));
+    q[2] = (unsigned char)(ss2 < 0 ? 0 : (ss2 > 255 ? 255 : ss2));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ColorJitter: four per-pixel ops in a per-sample order; contrast needs the image's mean luminance first
+// ---------------------------------------------------------------------------------------------
+struct Px { int r, g, b; };
+
+__device__ __forceinline__ int rgb2l(const Px& p) { return (p.r * 19595 + p.g * 38470 + p.b * 7471 + 0x8000) >> 16; }  // Convert.c
+
+// Blend.c ImagingBlend(in1 = degenerate, in2 = image, alpha): float arithmetic, separate multiply and add (no FMA: C float)
+__device__ __forceinline__ int blend1(int deg, int v, float a, bool interp) {
+  const float t = __fadd_rn((float)deg, __fmul_rn(a, __fsub_rn((float)v, (float)deg)));
+  if (interp) return (int)t;  // 0 <= alpha <= 1: (UINT8) cast, truncation
+  return t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (int)t);
+}
+__device__ __forceinline__ Px blend3(int dr, int dg, int db, const Px& p, float a) {
+  const bool interp = a >= 0.0f && a <= 1.0f;
+  return Px{blend1(dr, p.r, a, interp), blend1(dg, p.g, a, interp), blend1(db, p.b, a, interp)};
+}
+
+// Convert.c rgb2hsv_row / hsv2rgb_row with the C source's float / double promotions (see oracle/augment_ref.py)
+__device__ __forceinline__ Px hue_shift(const Px& p, int dh) {
+  int maxc = max(p.r, max(p.g, p.b)), minc = min(p.r, min(p.g, p.b));
+  int uh = 0, us = 0;
+  const int uv = maxc;
+  if (minc != maxc) {
+    const float cr = (float)(maxc - minc);
+    const float s = __fdiv_rn(cr, (float)maxc);
+    const float rc = __fdiv_rn((float)(maxc - p.r), cr), gc = __fdiv_rn((float)(maxc - p.g), cr), bc = __fdiv_rn((float)(maxc - p.b), cr);
+    float h;
+    if (p.r == maxc) h = __fsub_rn(bc, gc);
+    else if (p.g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+    else h = (float)(4.0 + (double)gc - (double)rc);
+    h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+    const int ih = (int)((double)h * 255.0), is = (int)((double)s * 255.0);
+    uh = ih < 0 ? 0 : (ih > 255 ? 255 : ih);
+    us = is < 0 ? 0 : (is > 255 ? 255 : is);
+  }
+  uh = (uh + dh) & 255;  // functional_pil.adjust_hue: np_h += np.uint8(hue_factor * 255), uint8 wrap-around
+  if (us == 0) return Px{uv, uv, uv};
+  const float fh = __fdiv_rn(__fmul_rn((float)uh, 6.0f), 255.0f);
+  const int i = (int)floorf(fh);
+  const float f = __fsub_rn(fh, (float)i);
+  const float fs = __fdiv_rn((float)us, 255.0f), fv = (float)uv;
+  auto rnd = [](float t) { const double r = floor((double)t + 0.5); return r < 0.0 ? 0 : (r > 255.0 ? 255 : (int)r); };
+  const int pp = rnd(__fmul_rn(fv, __fsub_rn(1.0f, fs)));
+  const int qq = rnd(__fmul_rn(fv, __fsub_rn(1.0f, __fmul_rn(fs, f))));
+  const int tt = rnd(__fmul_rn(fv, __fsub_rn(1.0f, __fmul_rn(fs, __fsub_rn(1.0f, f)))));
+  switch (i % 6) {
+    case 0: return Px{uv, tt, pp};
+    case 1: return Px{qq, uv, pp};
+    case 2: return Px{pp, uv, tt};
+    case 3: return Px{pp, qq, uv};
+    case 4: return Px{tt, pp, uv};
+    default: return Px{uv, pp, qq};
+  }
+}
+
+// per-sample jitter record: order[4] (0 brightness, 1 contrast, 2 saturation, 3 hue; -1 = skip), factors, hue shift (uint8)
+struct Jitter {
+  int order[4];
+  float brightness, contrast, saturation;
+  int hue_shift;
+};
+
+__device__ __forceinline__ Px jitter_op(const Px& p, int op, const Jitter& j, int mean_l) {
+  switch (op) {
+    case 0: return blend3(0, 0, 0, p, j.brightness);
+    case 1: return blend3(mean_l, mean_l, mean_l, p, j.contrast);
+    case 2: { const int l = rgb2l(p); return blend3(l, l, l, p, j.saturation); }
+    case 3: return hue_shift(p, j.hue_shift);
+    default: return p;
+  }
+}
+
+// pass 1: luminance sum of the image as it stands right before its contrast op (exact integer sum: order-independent)
+__global__ __launch_bounds__(256) void jitter_lsum_kernel(const unsigned char* __restrict__ src, const Jitter* __restrict__ jit,
+                                                          unsigned long long* __restrict__ lsum, int B, int HW) {
+  __shared__ unsigned long long part[4];
+  const int b = blockIdx.y;
+  const Jitter j = jit[b];
+  int npre = -1;
+  for (int t = 0; t < 4; ++t)
+    if (j.order[t] == 1) npre = t;
+  if (npre < 0) return;  // no contrast op for this sample
+  unsigned long long acc = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const unsigned char* p = src + ((long)b * HW + i) * 3;
+    Px x{p[0], p[1], p[2]};
+    for (int t = 0; t < npre; ++t) x = jitter_op(x, j.order[t], j, 0);
+    acc += (unsigned)rgb2l(x);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(lsum + b, part[0] + part[1] + part[2] + part[3]);
+}
+
+// pass 2: the whole chain (ImageStat mean = sum / count in double, int(mean + 0.5))
+__global__ __launch_bounds__(256) void jitter_apply_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                           const Jitter* __restrict__ jit,
+                                                           const unsigned long long* __restrict__ lsum, int B, int HW) {
+  const int b = blockIdx.y;
+  const Jitter j = jit[b];
+  const int mean_l = (int)((double)lsum[b] / (double)HW + 0.5);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+    const unsigned char* p = src + ((long)b * HW + i) * 3;
+    Px x{p[0], p[1], p[2]};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) x = jitter_op(x, j.order[t], j, mean_l);
+    unsigned char* q = dst + ((long)b * HW + i) * 3;
+    q[0] = (unsigned char)x.r; q[1] = (unsigned char)x.g; q[2] = (unsigned char)x.b;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GaussianBlur: separable, reflect padding, f32 taps per sample, taps summed in index order with separate multiply / add
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+// rows: u8 [B][H][W][3] -> f32 [B][H][W][3]
+__global__ __launch_bounds__(256) void blur_rows_kernel(const unsigned char* __restrict__ src, float* __restrict__ tmp,
+                                                        const float* __restrict__ taps, int ksize, int B, int H, int W) {
+  const long total = (long)B * H * W;
+  const int r = ksize >> 1;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int x = id % W;
+    const long row = id / W;  // b * H + y
+    const int b = row / H;
+    const float* k = taps + (long)b * ksize;
+    const unsigned char* line = src + row * W * 3;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int t = 0; t < ksize; ++t) {
+      const unsigned char* p = line + reflect(x + t - r, W) * 3;
+      const float kk = k[t];
+      a0 = __fadd_rn(a0, __fmul_rn(kk, (float)p[0]));
+      a1 = __fadd_rn(a1, __fmul_rn(kk, (float)p[1]));
+      a2 = __fadd_rn(a2, __fmul_rn(kk, (float)p[2]));
+    }
+    float* q = tmp + id * 3;
+    q[0] = a0; q[1] = a1; q[2] = a2;
+  }
+}
+
+// columns: f32 [B][H][W][3] -> u8, rint (half to even, as torch.round) and clamp
+__global__ __launch_bounds__(256) void blur_cols_kernel(const float* __restrict__ tmp, unsigned char* __restrict__ dst,
+                                                        const float* __restrict__ taps, int ksize, int B, int H, int W) {
+  const long total = (long)B * H * W;
+  const int r = ksize >> 1;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int x = id % W;
+    const int y = (id / W) % H;
+    const int b = id / ((long)W * H);
+    const float* k = taps + (long)b * ksize;
+    const float* img = tmp + (long)b * H * W * 3;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int t = 0; t < ksize; ++t) {
+      const float* p = img + ((long)reflect(y + t - r, H) * W + x) * 3;
+      const float kk = k[t];
+      a0 = __fadd_rn(a0, __fmul_rn(kk, p[0]));
+      a1 = __fadd_rn(a1, __fmul_rn(kk, p[1]));
+      a2 = __fadd_rn(a2, __fmul_rn(kk, p[2]));
+    }
+    unsigned char* q = dst + id * 3;
+    a0 = fminf(fmaxf(rintf(a0), 0.f), 255.f); a1 = fminf(fmaxf(rintf(a1), 0.f), 255.f); a2 = fminf(fmaxf(rintf(a2), 0.f), 255.f);
+    q[0] = (unsigned char)a0; q[1] = (unsigned char)a1; q[2] = (unsigned char)a2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// flips + rotation (Pillow affine_fixed, nearest, fill 0) + ToTensor + Normalize -> f32 NCHW, or the rotated u8 frame
+// ---------------------------------------------------------------------------------------------
+// geom[b] = {mode, a0, a1, a2, a3, a4, a5, flips}: mode 0 = 16.16 fixed-point inverse map (xin = (a2 + a0 x + a1 y) >> 16, ...),
+// 1 = identity, 2 = 180 degrees, 3 = 90 degrees (H == W), 4 = 270 degrees -- Image.rotate's transpose fast paths
+struct Geom { int mode, a0, a1, a2, a3, a4, a5, flips; };
+
+__device__ __forceinline__ bool geom_source(const Geom& g, int x, int y, int H, int W, int& sx, int& sy) {
+  int xin, yin;
+  switch (g.mode) {
+    case 1: xin = x; yin = y; break;
+    case 2: xin = W - 1 - x; yin = H - 1 - y; break;
+    case 3: xin = W - 1 - y; yin = x; break;   // np.rot90(k=1): out[y][x] = in[x][W-1-y]
+    case 4: xin = y; yin = H - 1 - x; break;   // np.rot90(k=3): out[y][x] = in[H-1-x][y]
+    default: {
+      xin = (g.a2 + g.a0 * x + g.a1 * y) >> 16;
+      yin = (g.a5 + g.a3 * x + g.a4 * y) >> 16;
+    }
+  }
+  if (xin < 0 || xin >= W || yin < 0 || yin >= H) return false;
+  // the rotation reads the FLIPPED image (transforms.py:241-243: flips come first)
+  sx = (g.flips & 1) ? W - 1 - xin : xin;
+  sy = (g.flips & 2) ? H - 1 - yin : yin;
+  return true;
+}
+
+template <bool TO_F32>
+__global__ __launch_bounds__(256) void geom_kernel(const unsigned char* __restrict__ src, const Geom* __restrict__ geom,
+                                                   void* __restrict__ dst, int B, int H, int W, f32x4 mean, f32x4 stdv) {
+  const long total = (long)B * H * W;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int x = id % W;
+    const int y = (id / W) % H;
+    const int b = id / ((long)W * H);
+    const Geom g = geom[b];
+    int sx, sy, v0 = 0, v1 = 0, v2 = 0;  // fillcolor 0
+    if (geom_source(g, x, y, H, W, sx, sy)) {
+      const unsigned char* p = src + (((long)b * H + sy) * W + sx) * 3;
+      v0 = p[0]; v1 = p[1]; v2 = p[2];
+    }
+    if constexpr (TO_F32) {
+      float* out = reinterpret_cast<float*>(dst);
+      const long plane = (long)H * W;
+      const long o = (long)b * 3 * plane + (long)y * W + x;
+      out[o] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v0, 255.0f), mean[0]), stdv[0]);
+      out[o + plane] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v1, 255.0f), mean[1]), stdv[1]);
+      out[o + 2 * plane] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)v2, 255.0f), mean[2]), stdv[2]);
+    } else {
+      unsigned char* q = reinterpret_cast<unsigned char*>(dst) + id * 3;
+      q[0] = (unsigned char)v0; q[1] = (unsigned char)v1; q[2] = (unsigned char)v2;
+    }
+  }
+}
+
+}  // namespace
+
+static_assert(sizeof(Jitter) == sizeof(pm_aug_jitter), "pm_aug_jitter layout");
+static_assert(sizeof(Geom) == sizeof(pm_aug_geom), "pm_aug_geom layout");
+
+extern "C" int pm_aug_resize_u8(const unsigned char* src, unsigned char* tmp, unsigned char* dst, const int* bounds_x,
+                                const int* taps_x, int ksize_x, const int* bounds_y, const int* taps_y, int ksize_y, int B, int Hs,
+                                int Ws, int Ho, int Wo, void* stream) {
+  if (!src || !dst) return PM_EINVAL;
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0) return PM_ESHAPE;
+  const bool do_x = Wo != Ws, do_y = Ho != Hs;
+  if ((do_x && (!bounds_x || !taps_x || ksize_x <= 0)) || (do_y && (!bounds_y || !taps_y || ksize_y <= 0))) return PM_EINVAL;
+  if (do_x && do_y && !tmp) return PM_EINVAL;
+  hipStream_t s = pm_stream(stream);
+  if (!do_x && !do_y) {
+    if (hipMemcpyAsync(dst, src, (size_t)B * Hs * Ws * 3, hipMemcpyDeviceToDevice, s) != hipSuccess) return PM_ELAUNCH;
+    return PM_OK;
+  }
+  const unsigned char* cur = src;
+  if (do_x) {  // horizontal pass first (ImagingResampleInner), into tmp when a vertical pass follows
+    unsigned char* o = do_y ? tmp : dst;
+    hipLaunchKernelGGL(resample_kernel, dim3(aug_grid((long)B * Hs * Wo)), dim3(256), 0, s, cur, o, bounds_x, taps_x, ksize_x, B, Hs,
+                       Ws, Hs, Wo, 0);
+    cur = o;
+  }
+  if (do_y)
+    hipLaunchKernelGGL(resample_kernel, dim3(aug_grid((long)B * Ho * Wo)), dim3(256), 0, s, cur, dst, bounds_y, taps_y, ksize_y, B,
+                       Hs, Wo, Ho, Wo, 1);
+  return pm_check_launch();
+}
+
+extern "C" int pm_aug_color_jitter_u8(const unsigned char* src, unsigned char* dst, const pm_aug_jitter* jitter,
+                                      unsigned long long* lsum, int B, int H, int W, void* stream) {
+  if (!src || !dst || !jitter || !lsum) return PM_EINVAL;
+  if (B <= 0 || H <= 0 || W <= 0) return PM_ESHAPE;
+  hipStream_t s = pm_stream(stream);
+  if (hipMemsetAsync(lsum, 0, (size_t)B * sizeof(unsigned long long), s) != hipSuccess) return PM_ELAUNCH;
+  const int HW = H * W;
+  int gx = (HW + 256 * 8 - 1) / (256 * 8);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(jitter_lsum_kernel, dim3(gx, B), dim3(256), 0, s, src, reinterpret_cast<const Jitter*>(jitter), lsum, B, HW);
+  hipLaunchKernelGGL(jitter_apply_kernel, dim3(gx, B), dim3(256), 0, s, src, dst, reinterpret_cast<const Jitter*>(jitter), lsum, B,
+                     HW);
+  return pm_check_launch();
+}
+
+extern "C" int pm_aug_gaussian_blur_u8(const unsigned char* src, float* tmp, unsigned char* dst, const float* taps, int ksize, int B,
+                                       int H, int W, void* stream) {
+  if (!src || !tmp || !dst || !taps) return PM_EINVAL;
+  if (B <= 0 || H <= 0 || W <= 0 || ksize <= 0 || !(ksize & 1)) return PM_ESHAPE;
+  if ((ksize >> 1) >= H || (ksize >> 1) >= W) return PM_ESHAPE;  // reflect padding needs pad < size (as torch does)
+  hipStream_t s = pm_stream(stream);
+  const int g = aug_grid((long)B * H * W);
+  hipLaunchKernelGGL(blur_rows_kernel, dim3(g), dim3(256), 0, s, src, tmp, taps, ksize, B, H, W);
+  hipLaunchKernelGGL(blur_cols_kernel, dim3(g), dim3(256), 0, s, tmp, dst, taps, ksize, B, H, W);
+  return pm_check_launch();
+}
+
+extern "C" int pm_aug_geometry_u8(const unsigned char* src, const pm_aug_geom* geom, void* dst, int to_f32, int B, int H, int W,
+                                  float mean_r, float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream) {
+  if (!src || !geom || !dst) return PM_EINVAL;
+  if (B <= 0 || H <= 0 || W <= 0) return PM_ESHAPE;
+  if (to_f32 && (!(std_r > 0.f) || !(std_g > 0.f) || !(std_b > 0.f))) return PM_EINVAL;
+  const int g = aug_grid((long)B * H * W);
+  const f32x4 mean{mean_r, mean_g, mean_b, 0.f}, stdv{std_r, std_g, std_b, 1.f};
+  if (to_f32)
+    hipLaunchKernelGGL(geom_kernel<true>, dim3(g), dim3(256), 0, pm_stream(stream), src, reinterpret_cast<const Geom*>(geom), dst, B,
+                       H, W, mean, stdv);
+  else
+    hipLaunchKernelGGL(geom_kernel<false>, dim3(g), dim3(256), 0, pm_stream(stream), src, reinterpret_cast<const Geom*>(geom), dst, B,
+                       H, W, mean, stdv);
+  return pm_check_launch();
+}

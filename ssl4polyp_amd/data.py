@@ -5,7 +5,9 @@ The reference decodes, resizes and augments with PIL on DataLoader workers and h
 HWC frames; `DevicePrefetcher` stages them through pinned host buffers, copies them on a dedicated stream while the
 previous step computes (a uint8 batch is a quarter of the float32 bytes on PCIe) and runs the last three transform
 stages on the device in one HBM-bound kernel (`pm_preprocess_u8`): optional horizontal / vertical flip, ToTensor,
-Normalize -- bit-exact with torchvision's float32 arithmetic.
+Normalize -- bit-exact with torchvision's float32 arithmetic.  `DeviceAugmenter` (round 3) moves the rest of the train transform
+there as well -- Resize, ColorJitter, GaussianBlur((25, 25)), flips, RandomRotation(180) -- with Pillow's own integer / float
+arithmetic (`pm_aug_*`, csrc/pm_augment.hip), so the workers are left with JPEG decoding only.
 """
 from __future__ import annotations
 
@@ -41,6 +43,192 @@ def preprocess_u8(frames: torch.Tensor, flips: Optional[torch.Tensor] = None, me
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# train-time augmentation on the device (classification/data/transforms.py:234-246)
+# ---------------------------------------------------------------------------------------------------------------------
+def _resample_coeffs(in_size: int, out_size: int):
+    """Pillow Resample.c precompute_coeffs (bilinear filter, support 1, antialiased) + normalize_coeffs_8bpc: for every output
+    index the first source index, the tap count and the 22-bit fixed-point taps.  Double arithmetic, as in the C source."""
+    import math
+
+    import numpy as np
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.float64)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = np.array([max(0.0, 1.0 - abs((x + xmin - center + 0.5) * ss)) for x in range(xmax)], dtype=np.float64)
+        ww = 0.0
+        for v in w:   # (the C loop's summation order)
+            ww += v
+        if ww != 0.0:
+            w = w / ww
+        kk[xx, :xmax] = w
+        bounds[xx] = (xmin, xmax)
+    taps = np.where(kk < 0, (-0.5 + kk * (1 << 22)).astype(np.int64), (0.5 + kk * (1 << 22)).astype(np.int64)).astype(np.int32)
+    return bounds, taps, ksize
+
+
+def _gaussian_taps(ksize: int, sigma):
+    """torchvision functional_tensor._get_gaussian_kernel1d in float32, one row per sigma."""
+    import numpy as np
+    half = (ksize - 1) * 0.5
+    x = np.linspace(-half, half, ksize, dtype=np.float32)
+    rows = []
+    for sg in sigma:
+        pdf = np.exp(np.float32(-0.5) * (x / np.float32(sg)) ** 2).astype(np.float32)
+        rows.append((pdf / pdf.sum(dtype=np.float32)).astype(np.float32))
+    return np.stack(rows)
+
+
+def _rotation_geom(angle_deg: float, w: int, h: int, flips: int):
+    """Image.rotate(angle, NEAREST, expand=False, center=None) -> the pm_aug_geom record: Pillow's inverse affine map about the
+    image centre (coefficients rounded to 15 decimals, then FIX(v) = floor(v * 65536 + 0.5), half-pixel offsets folded into
+    a2 / a5 as Geometry.c affine_fixed does), or one of its transpose fast paths."""
+    import math
+    ang = angle_deg % 360.0
+    if ang == 0:
+        return (1, 0, 0, 0, 0, 0, 0, flips)
+    if ang == 180:
+        return (2, 0, 0, 0, 0, 0, 0, flips)
+    if ang in (90, 270) and w == h:
+        return (3 if ang == 90 else 4, 0, 0, 0, 0, 0, 0, flips)
+    rad = -math.radians(ang)
+    m = [round(math.cos(rad), 15), round(math.sin(rad), 15), 0.0, round(-math.sin(rad), 15), round(math.cos(rad), 15), 0.0]
+    cx, cy = w / 2.0, h / 2.0
+    m[2] = m[0] * -cx + m[1] * -cy + m[2] + cx
+    m[5] = m[3] * -cx + m[4] * -cy + m[5] + cy
+    fix = lambda v: int(math.floor(v * 65536.0 + 0.5))
+    return (0, fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]),
+            fix(m[5] + m[3] * 0.5 + m[4] * 0.5), flips)
+
+
+def draw_train_params(B: int, generator: Optional[torch.Generator] = None, brightness=0.4, contrast=0.5, saturation=0.25, hue=0.01,
+                      sigma=(0.001, 2.0), flip_p=0.5, degrees=180.0) -> dict:
+    """The random draws of the reference's train transform for B samples (transforms.py:238-245; torchvision 0.10 get_params:
+    ColorJitter -> a permutation of the four ops + one uniform factor each, GaussianBlur -> sigma ~ U(0.001, 2),
+    RandomHorizontal/VerticalFlip -> rand < 0.5, RandomRotation -> angle ~ U(-180, 180)).  The reference draws per image inside
+    its DataLoader workers; here one host generator serves the batch (the streams differ, the distributions do not)."""
+    g = generator
+    u = lambda lo, hi: torch.empty(B, dtype=torch.float64).uniform_(lo, hi, generator=g)
+    order = torch.stack([torch.randperm(4, generator=g) for _ in range(B)])
+    return {"order": order.numpy(), "brightness": u(max(0.0, 1 - brightness), 1 + brightness).numpy(),
+            "contrast": u(max(0.0, 1 - contrast), 1 + contrast).numpy(), "saturation": u(max(0.0, 1 - saturation), 1 + saturation).numpy(),
+            "hue": u(-hue, hue).numpy(), "sigma": u(sigma[0], sigma[1]).numpy(),
+            "hflip": (torch.rand(B, generator=g) < flip_p).numpy(), "vflip": (torch.rand(B, generator=g) < flip_p).numpy(),
+            "angle": u(-degrees, degrees).numpy()}
+
+
+class DeviceAugmenter:
+    """The reference's whole train transform after decoding, on the device: [Resize ->] ColorJitter -> GaussianBlur(25) -> flips
+    -> RandomRotation(180) -> ToTensor -> Normalize, six launches over a uint8 batch (pm_aug_*), f32 NCHW out.  The host does
+    what is scalar and per sample: the random draws, Pillow's resample taps (cached per size pair), the blur taps, the rotation's
+    fixed-point matrix -- a few hundred bytes per batch, uploaded from pinned memory on the caller's stream."""
+
+    KSIZE = 25  # transforms.py:239
+
+    def __init__(self, device, size: int = 224, mean: Sequence[float] = IMAGENET_MEAN, std: Sequence[float] = IMAGENET_STD):
+        self.device, self.size, self.mean, self.std = torch.device(device), int(size), tuple(mean), tuple(std)
+        self._coeffs = {}
+        self._bufs = {}
+
+    def _buf(self, name, shape, dtype):
+        t = self._bufs.get(name)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = self._bufs[name] = torch.empty(shape, dtype=dtype, device=self.device)
+        return t
+
+    def _upload(self, name, arr):
+        """numpy -> device through a pinned staging tensor kept per name (non-blocking; rewritten only after a host sync of the
+        previous copy's event)."""
+        import numpy as np
+        host = torch.from_numpy(np.ascontiguousarray(arr))
+        slot = self._bufs.get("pin_" + name)
+        if slot is None or slot[0].shape != host.shape or slot[0].dtype != host.dtype:
+            slot = self._bufs["pin_" + name] = [torch.empty(host.shape, dtype=host.dtype).pin_memory(), None]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0].copy_(host)
+        dev = self._buf("dev_" + name, host.shape, host.dtype)
+        dev.copy_(slot[0], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        slot[1] = ev
+        return dev
+
+    def resize(self, frames: torch.Tensor) -> torch.Tensor:
+        """uint8 [B, Hs, Ws, 3] -> uint8 [B, size, size, 3] (T.Resize((size, size)) on PIL images)."""
+        B, Hs, Ws, _ = frames.shape
+        S = self.size
+        if (Hs, Ws) == (S, S):
+            return frames
+        key = (Hs, Ws, S)
+        c = self._coeffs.get(key)
+        if c is None:
+            bx, tx, kx = _resample_coeffs(Ws, S)
+            by, ty, ky = _resample_coeffs(Hs, S)
+            c = self._coeffs[key] = tuple(torch.from_numpy(a).to(self.device) for a in (bx, tx, by, ty)) + (kx, ky)
+        bx, tx, by, ty, kx, ky = c
+        tmp = self._buf("rs_tmp", (B, Hs, S, 3), torch.uint8)
+        out = self._buf("rs_out", (B, S, S, 3), torch.uint8)
+        lib = _lib.load()
+        _lib.check(lib.pm_aug_resize_u8(frames.data_ptr(), tmp.data_ptr(), out.data_ptr(), bx.data_ptr(), tx.data_ptr(), kx,
+                                        by.data_ptr(), ty.data_ptr(), ky, B, Hs, Ws, S, S,
+                                        torch.cuda.current_stream(self.device).cuda_stream), "pm_aug_resize_u8")
+        return out
+
+    def __call__(self, frames: torch.Tensor, params: Optional[dict] = None, generator: Optional[torch.Generator] = None,
+                 to_f32: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """frames uint8 [B, H, W, 3] on the device.  Returns f32 [B, 3, size, size] (normalised) or, with to_f32=False, the
+        augmented uint8 frames [B, size, size, 3] (written into `out` when given)."""
+        import numpy as np
+        if frames.dtype != torch.uint8 or frames.ndim != 4 or frames.shape[-1] != 3 or not frames.is_contiguous():
+            raise ValueError("frames must be a contiguous uint8 [B, H, W, 3] tensor")
+        if not frames.is_cuda:
+            raise _lib.PolypMaeError("DeviceAugmenter runs on the GPU only (no CPU fallback)")
+        lib = _lib.load()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        x = self.resize(frames)
+        B, H, W, _ = x.shape
+        p = params if params is not None else draw_train_params(B, generator)
+        # -- ColorJitter
+        jit = np.zeros((B, 8), dtype=np.int32)
+        jit[:, :4] = np.asarray(p["order"], dtype=np.int32)
+        jit[:, 4:7] = np.stack([np.asarray(p[k], dtype=np.float32) for k in ("brightness", "contrast", "saturation")], 1).view(np.int32)
+        jit[:, 7] = [int(np.int64(float(h) * 255)) & 0xFF for h in p["hue"]]   # np.uint8(hue_factor * 255): C cast, wraps
+        jit_d = self._upload("jit", jit)
+        lsum = self._buf("lsum", (B,), torch.int64)
+        a = self._buf("aug_a", (B, H, W, 3), torch.uint8)
+        _lib.check(lib.pm_aug_color_jitter_u8(x.data_ptr(), a.data_ptr(), jit_d.data_ptr(), lsum.data_ptr(), B, H, W, st),
+                   "pm_aug_color_jitter_u8")
+        # -- GaussianBlur((25, 25))
+        taps_d = self._upload("taps", _gaussian_taps(self.KSIZE, p["sigma"]))
+        tmp = self._buf("blur_tmp", (B, H, W, 3), torch.float32)
+        b = self._buf("aug_b", (B, H, W, 3), torch.uint8)
+        _lib.check(lib.pm_aug_gaussian_blur_u8(a.data_ptr(), tmp.data_ptr(), b.data_ptr(), taps_d.data_ptr(), self.KSIZE, B, H, W,
+                                               st), "pm_aug_gaussian_blur_u8")
+        # -- flips + rotation (+ ToTensor + Normalize)
+        geom = np.array([_rotation_geom(float(p["angle"][i]), W, H, int(bool(p["hflip"][i])) | (int(bool(p["vflip"][i])) << 1))
+                         for i in range(B)], dtype=np.int32)
+        geom_d = self._upload("geom", geom)
+        want = (B, 3, H, W) if to_f32 else (B, H, W, 3)
+        if out is None:
+            out = torch.empty(want, dtype=torch.float32 if to_f32 else torch.uint8, device=self.device)
+        elif tuple(out.shape) != want or out.dtype != (torch.float32 if to_f32 else torch.uint8) or not out.is_contiguous():
+            raise ValueError("`out` has the wrong shape / dtype")
+        m, s = self.mean, self.std
+        _lib.check(lib.pm_aug_geometry_u8(b.data_ptr(), geom_d.data_ptr(), out.data_ptr(), 1 if to_f32 else 0, B, H, W, float(m[0]),
+                                          float(m[1]), float(m[2]), float(s[0]), float(s[1]), float(s[2]), st),
+                   "pm_aug_geometry_u8")
+        return out
+
+
 class DevicePrefetcher:
     """Wraps a loader that yields (frames uint8 [B,H,W,3] on the host, *rest): copies batch i+1 to the device on a
     side stream (pinned staging, two slots) while batch i is consumed, and yields (imgs float32 [B,3,H,W] on the
@@ -49,9 +237,13 @@ class DevicePrefetcher:
     RandomVerticalFlip of the reference's train transform) from `generator`."""
 
     def __init__(self, loader: Iterable, device, mean: Sequence[float] = IMAGENET_MEAN, std: Sequence[float] = IMAGENET_STD,
-                 flip_p: float = 0.0, generator: Optional[torch.Generator] = None):
+                 flip_p: float = 0.0, generator: Optional[torch.Generator] = None, augment: Optional["DeviceAugmenter"] = None):
+        """augment: a DeviceAugmenter -> the loader may yield decoded frames of any (batch-uniform) size and the WHOLE train
+        transform of the reference (Resize, ColorJitter, GaussianBlur(25), flips, RandomRotation(180), ToTensor, Normalize) runs
+        on the copy stream; `flip_p` is then ignored (the augmenter draws its own flips from `generator`)."""
         self.loader, self.device = loader, torch.device(device)
         self.mean, self.std, self.flip_p, self.generator = mean, std, float(flip_p), generator
+        self.augment = augment
         self._pinned = [None, None]
         self._flip_pin = [None, None]   # per slot: pinned flip flags
         self._dev = [None, None]        # per slot: (uint8 frames, float32 images) on the device
@@ -75,7 +267,7 @@ class DevicePrefetcher:
                 self._pinned[slot] = pin
             pin.copy_(frames)
         flips = None
-        if self.flip_p > 0:
+        if self.flip_p > 0 and self.augment is None:
             r = torch.rand(2, frames.shape[0], generator=self.generator)
             f8 = ((r[0] < self.flip_p).to(torch.uint8) | ((r[1] < self.flip_p).to(torch.uint8) << 1))
             # pinned too: a pageable host-to-device copy is synchronous and would stall the enqueue of the step
@@ -89,15 +281,19 @@ class DevicePrefetcher:
         bufs = self._dev[slot]
         if bufs is None or bufs[0].shape != frames.shape:
             B, H, W, _ = frames.shape
+            S = self.augment.size if self.augment is not None else None
             bufs = (torch.empty(frames.shape, dtype=torch.uint8, device=self.device),
-                    torch.empty(B, 3, H, W, dtype=torch.float32, device=self.device))
+                    torch.empty((B, 3, S, S) if S else (B, 3, H, W), dtype=torch.float32, device=self.device))
             self._dev[slot] = bufs
         with torch.cuda.stream(self._stream):
             if self._consumed[slot] is not None:
                 self._stream.wait_event(self._consumed[slot])
             bufs[0].copy_(pin, non_blocking=True)
-            fl = flips.to(self.device, non_blocking=True) if flips is not None else None
-            imgs = preprocess_u8(bufs[0], fl, self.mean, self.std, out=bufs[1])
+            if self.augment is not None:
+                imgs = self.augment(bufs[0], generator=self.generator, out=bufs[1])
+            else:
+                fl = flips.to(self.device, non_blocking=True) if flips is not None else None
+                imgs = preprocess_u8(bufs[0], fl, self.mean, self.std, out=bufs[1])
             rest_dev = tuple(t.to(self.device, non_blocking=True) if torch.is_tensor(t) else t for t in rest)
             ev = torch.cuda.Event()
             ev.record(self._stream)

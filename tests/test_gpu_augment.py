@@ -1,0 +1,150 @@
+"""Device-side train augmentation (pm_aug_*, ssl4polyp_amd.data.DeviceAugmenter) against oracle/augment_ref.py -- itself pinned
+against Pillow (tests/test_augment_cpu.py) -- BIT FOR BIT: byte / integer work, no tolerance.
+Reference: classification/data/transforms.py:234-246 (Resize, ColorJitter, GaussianBlur((25,25)), flips, RandomRotation(180),
+ToTensor, Normalize)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _frames(B, H, W, seed, smooth=True):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if not smooth:
+        return rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    out = []
+    for b in range(B):
+        base = np.stack([128 + 100 * np.sin(xx / (9.0 + b) + c) * np.cos(yy / 13.0 - c - b) for c in range(3)], -1)
+        out.append(np.clip(base + rng.normal(0, 15, (H, W, 3)), 0, 255))
+    return np.stack(out).astype(np.uint8)
+
+
+def _params(B, seed, **over):
+    from ssl4polyp_amd.data import draw_train_params
+    p = draw_train_params(B, torch.Generator().manual_seed(seed))
+    p.update(over)
+    return p
+
+
+@pytest.mark.parametrize("Hs,Ws", [(180, 240), (97, 224), (224, 133), (300, 260), (224, 224)])
+def test_resize_bit_exact(Hs, Ws):
+    from oracle import augment_ref as R
+    from ssl4polyp_amd.data import DeviceAugmenter
+    x = _frames(3, Hs, Ws, 7)
+    aug = DeviceAugmenter(DEV, size=224)
+    got = aug.resize(torch.from_numpy(x).to(DEV)).cpu().numpy()
+    assert np.array_equal(got, R.resize_bilinear(x, 224, 224))
+
+
+@pytest.mark.parametrize("smooth", [True, False])
+def test_color_jitter_blur_geometry_stages_bit_exact(smooth):
+    """Every stage on its own (the stage outputs are what a mismatch would be traced to), at 224 x 224, B = 5 with the five
+    samples drawing different op orders / factors / sigmas / angles; plus the special rotations and extreme factors."""
+    from oracle import augment_ref as R
+    from ssl4polyp_amd import _lib
+    from ssl4polyp_amd.data import DeviceAugmenter, _gaussian_taps, _rotation_geom
+    B, H, W = 5, 224, 224
+    x = _frames(B, H, W, 11, smooth)
+    p = _params(B, 3)
+    p["brightness"][0], p["contrast"][1], p["saturation"][2], p["hue"][3] = 1.0, 0.5, 1.25, -0.01   # interval ends
+    p["angle"][:4] = (0.0, 180.0, 90.0, -90.0)                                                       # Image.rotate fast paths
+    lib = _lib.load()
+    st = torch.cuda.current_stream(DEV).cuda_stream
+    xd = torch.from_numpy(x).to(DEV)
+    # ColorJitter
+    jit = np.zeros((B, 8), dtype=np.int32)
+    jit[:, :4] = p["order"]
+    jit[:, 4:7] = np.stack([np.asarray(p[k], dtype=np.float32) for k in ("brightness", "contrast", "saturation")], 1).view(np.int32)
+    jit[:, 7] = [int(np.int64(float(h) * 255)) & 0xFF for h in p["hue"]]
+    jd = torch.from_numpy(jit).to(DEV)
+    lsum = torch.zeros(B, dtype=torch.int64, device=DEV)
+    a = torch.empty_like(xd)
+    _lib.check(lib.pm_aug_color_jitter_u8(xd.data_ptr(), a.data_ptr(), jd.data_ptr(), lsum.data_ptr(), B, H, W, st), "jitter")
+    want = x.copy()
+    fns = [R.adjust_brightness, R.adjust_contrast, R.adjust_saturation, R.adjust_hue]
+    names = ["brightness", "contrast", "saturation", "hue"]
+    for b in range(B):
+        t = x[b:b + 1]
+        for op in p["order"][b]:
+            t = fns[int(op)](t, float(p[names[int(op)]][b]))
+        want[b] = t[0]
+    assert np.array_equal(a.cpu().numpy(), want), "ColorJitter"
+    # GaussianBlur
+    taps = torch.from_numpy(_gaussian_taps(25, p["sigma"])).to(DEV)
+    tmp = torch.empty(B, H, W, 3, dtype=torch.float32, device=DEV)
+    bl = torch.empty_like(xd)
+    _lib.check(lib.pm_aug_gaussian_blur_u8(a.data_ptr(), tmp.data_ptr(), bl.data_ptr(), taps.data_ptr(), 25, B, H, W, st), "blur")
+    want_b = np.concatenate([R.gaussian_blur(want[b:b + 1], 25, float(p["sigma"][b])) for b in range(B)])
+    assert np.array_equal(bl.cpu().numpy(), want_b), "GaussianBlur"
+    # flips + rotation, u8 out
+    geom = np.array([_rotation_geom(float(p["angle"][i]), W, H, int(p["hflip"][i]) | (int(p["vflip"][i]) << 1)) for i in range(B)],
+                    dtype=np.int32)
+    gd = torch.from_numpy(geom).to(DEV)
+    rot = torch.empty_like(xd)
+    _lib.check(lib.pm_aug_geometry_u8(bl.data_ptr(), gd.data_ptr(), rot.data_ptr(), 0, B, H, W, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0, st), "geom")
+    want_r = np.empty_like(want_b)
+    for b in range(B):
+        t = want_b[b:b + 1]
+        if p["hflip"][b]:
+            t = t[:, :, ::-1]
+        if p["vflip"][b]:
+            t = t[:, ::-1]
+        want_r[b] = R.rotate_nearest(np.ascontiguousarray(t), float(p["angle"][b]))[0]
+    assert np.array_equal(rot.cpu().numpy(), want_r), "flips + rotation"
+
+
+def test_device_augmenter_whole_chain_equals_oracle_then_to_tensor_normalize():
+    """Resize -> ColorJitter -> GaussianBlur -> flips -> rotation -> ToTensor -> Normalize through DeviceAugmenter, B = 6 frames of
+    300 x 260, against oracle.train_augment + oracle.input_ref.to_tensor_normalize: the f32 NCHW batch equals bit for bit."""
+    from oracle import augment_ref as R
+    from oracle.input_ref import to_tensor_normalize
+    from ssl4polyp_amd.data import DeviceAugmenter
+    B = 6
+    x = _frames(B, 300, 260, 21)
+    p = _params(B, 9)
+    aug = DeviceAugmenter(DEV, size=224)
+    got = aug(torch.from_numpy(x).to(DEV), params=p)
+    want_u8 = R.train_augment(R.resize_bilinear(x, 224, 224), p)
+    got_u8 = aug(torch.from_numpy(x).to(DEV), params=p, to_f32=False)
+    assert np.array_equal(got_u8.cpu().numpy(), want_u8)
+    assert got.shape == (B, 3, 224, 224) and torch.equal(got.cpu(), to_tensor_normalize(torch.from_numpy(want_u8)))
+    # drawing its own parameters from a generator: reproducible
+    g1, g2 = torch.Generator().manual_seed(4), torch.Generator().manual_seed(4)
+    assert torch.equal(aug(torch.from_numpy(x).to(DEV), generator=g1), aug(torch.from_numpy(x).to(DEV), generator=g2))
+
+
+def test_bad_arguments_are_refused():
+    from ssl4polyp_amd import _lib
+    lib = _lib.load()
+    z = torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device=DEV)
+    t = torch.zeros(1, 8, 8, 3, dtype=torch.float32, device=DEV)
+    taps = torch.zeros(1, 25, device=DEV)
+    st = torch.cuda.current_stream(DEV).cuda_stream
+    assert lib.pm_aug_gaussian_blur_u8(z.data_ptr(), t.data_ptr(), z.data_ptr(), taps.data_ptr(), 25, 1, 8, 8, st) == _lib.PM_ESHAPE  # pad >= size
+    assert lib.pm_aug_gaussian_blur_u8(z.data_ptr(), t.data_ptr(), z.data_ptr(), taps.data_ptr(), 4, 1, 8, 8, st) == _lib.PM_ESHAPE   # even kernel
+    assert lib.pm_aug_geometry_u8(z.data_ptr(), None, z.data_ptr(), 0, 1, 8, 8, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0, st) != 0
+
+
+def test_device_prefetcher_with_augmenter_feeds_a_model():
+    """DevicePrefetcher(augment=DeviceAugmenter): frames of a non-224 size in, the reference's whole train transform on the copy
+    stream, normalised f32 batches out, in loader order; the same generator seed reproduces the same batches."""
+    from ssl4polyp_amd.data import DeviceAugmenter, DevicePrefetcher
+    import ssl4polyp_amd as A
+    g = torch.Generator().manual_seed(8)
+    batches = [(torch.randint(0, 256, (3, 150, 200, 3), dtype=torch.uint8, generator=g), torch.arange(3) + 10 * i) for i in range(4)]
+
+    def run(seed):
+        out = []
+        pf = DevicePrefetcher(batches, DEV, augment=DeviceAugmenter(DEV), generator=torch.Generator().manual_seed(seed))
+        for imgs, labels in pf:
+            assert imgs.shape == (3, 3, 224, 224) and imgs.dtype == torch.float32 and labels.is_cuda
+            out.append((imgs.clone(), labels.clone()))
+        return out
+    a, b, c = run(1), run(1), run(2)
+    assert len(a) == 4 and all(torch.equal(x[1].cpu(), batches[i][1]) for i, x in enumerate(a))
+    assert all(torch.equal(x[0], y[0]) for x, y in zip(a, b)) and not torch.equal(a[0][0], c[0][0])
+    m = A.ViT_from_MAE(None, True, 2, False, None, embed_dim=64, depth=1, num_heads=2, out_token="cls").to(DEV)
+    assert m(a[0][0]).shape == (3, 2)
