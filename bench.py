@@ -69,6 +69,13 @@ def parse():
     ap.add_argument("--input", choices=["resident", "host"], default="resident",
                     help="resident (the contract: batch already in HBM) or host: uint8 HWC frames in pinned host memory, "
                          "copied and normalised on a side stream each step (PCIe-inclusive rate, DESIGN.md)")
+    ap.add_argument("--augment", choices=["none", "device"], default="none",
+                    help="with --input host: `device` feeds decoded 576x720 uint8 frames and runs the reference's whole train "
+                         "transform (Resize, ColorJitter, GaussianBlur(25), flips, RandomRotation(180), ToTensor, Normalize: "
+                         "classification/data/transforms.py:234-246) on the copy stream (data.DeviceAugmenter)")
+    ap.add_argument("--host-busy", type=int, default=0,
+                    help="also measure host enqueue time and step rate while this many spinning processes compete for the host's "
+                         "cores (the 8-ranks-on-one-host picture from a one-GPU box): reported as `busy_host`")
     ap.add_argument("--preheat", type=float, default=1.0,
                     help="seconds of untimed steps before the W warm-up steps (clock / power ramp after process start; 0 = none)")
     ap.add_argument("--finetune-mode", choices=["none", "head+1", "head+2", "full"], default="full",
@@ -560,13 +567,15 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
     host_pool, host_gen = [], torch.Generator().manual_seed(1234 + rank)
     host_input = args.input == "host" and headline
     if host_input:  # four decoded batches in pinned host memory, built outside the timed region
-        host_pool = [(torch.randint(0, 256, (batch, 224, 224, 3), dtype=torch.uint8, generator=host_gen).pin_memory(),
+        hw = (576, 720) if args.augment == "device" else (224, 224)   # decoded Hyperkvasir-like frames / already resized frames
+        host_pool = [(torch.randint(0, 256, (batch, *hw, 3), dtype=torch.uint8, generator=host_gen).pin_memory(),
                       (torch.rand(batch, generator=host_gen) < 0.5).long().pin_memory()) for _ in range(4)]
 
     def host_feed(n):
         # uint8 HWC frames + labels in pinned host memory -> DevicePrefetcher (H2D + flips + ToTensor + Normalize)
-        from ssl4polyp_amd.data import DevicePrefetcher
-        return DevicePrefetcher([host_pool[i % 4] for i in range(n)], device, flip_p=0.5, generator=host_gen)
+        from ssl4polyp_amd.data import DeviceAugmenter, DevicePrefetcher
+        aug = DeviceAugmenter(device) if args.augment == "device" else None
+        return DevicePrefetcher([host_pool[i % 4] for i in range(n)], device, flip_p=0.5, generator=host_gen, augment=aug)
 
     # The parity block compares at the freshly initialised weights (after tens of AdamW steps at lr 1e-3 on random labels
     # the outputs and gradients collapse towards zero and relative errors stop meaning anything), but runs AFTER the timed
@@ -637,6 +646,31 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    busy = None
+    if args.host_busy > 0 and headline and not host_input:
+        # N spinners pinned to nothing in particular: the scheduler shares the granted cores between them and this process
+        spin = [subprocess.Popen([sys.executable, "-c", "while True: pass"]) for _ in range(args.host_busy)]
+        try:
+            time.sleep(0.5)
+            torch.cuda.synchronize()
+            t_h = time.perf_counter()
+            for _ in range(3):
+                step()
+            enq_b = (time.perf_counter() - t_h) / 3
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt_b = time.perf_counter() - t_b
+            busy = {"spinning_processes": args.host_busy, "host_cpus": len(os.sched_getaffinity(0)),
+                    "host_enqueue_ms_per_step": round(enq_b * 1e3, 3), "value": round(batch * world * args.steps / dt_b, 2),
+                    "ms_per_step": round(dt_b / args.steps * 1e3, 3)}
+        finally:
+            for p in spin:   # exactly the PIDs started here
+                p.kill()
+            for p in spin:
+                p.wait()
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     step_ms = {"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3), "max": round(per_step[-1], 3),
                "first": round(marks[0].elapsed_time(marks[1]), 3), "last": round(marks[-2].elapsed_time(marks[-1]), 3)}
@@ -727,6 +761,8 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
                "roofline": roof}
         if parity is not None:
             rec["parity"] = parity
+        if busy is not None:
+            rec["busy_host"] = busy
         if eval_rec is not None:
             rec["eval_forward"] = eval_rec
         if light:  # trainable bytes the gradient all-reduce would carry in this mode (parallel.GradSync plan)
@@ -903,13 +939,17 @@ def main():
             "value": head["value"], "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision,
-            "data": "synthetic" if args.input == "resident" else "synthetic uint8 frames in pinned host memory (PCIe-inclusive)",
+            "data": "synthetic" if args.input == "resident" else
+                    ("synthetic uint8 frames in pinned host memory (PCIe-inclusive)" +
+                     (", 576x720, whole train transform on the device" if args.augment == "device" else "")),
             "config": head["config"], "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"], "step_ms": head["step_ms"],
             "preheat_steps": head["preheat_steps"],
             "roofline": head["roofline"],
         }
         if "parity" in head:
             out["parity"] = head["parity"]
+        if "busy_host" in head:
+            out["busy_host"] = head["busy_host"]
         if sub is not None:
             out["mae"] = {"metric": "training-step images/sec/node, ViT-B/16 224^2 (MAE pre-train)", "steps": args.steps,
                           "warmup": args.warmup, **sub}

@@ -224,6 +224,15 @@ int pm_aug_resize_u8(const unsigned char* src, unsigned char* tmp, unsigned char
                      int ksize_x, const int* bounds_y, const int* taps_y, int ksize_y, int B, int Hs, int Ws, int Ho, int Wo,
                      void* stream);
 
+/* RandomResizedCrop's arithmetic (mae/main_pretrain.py:157: RandomResizedCrop(224, scale=(0.2, 1.0), interpolation=bicubic) ->
+ * functional.resized_crop = img.crop(box).resize((out, out), BICUBIC)): every sample has its own crop box = (top, left, h, w)
+ * (i32 [B][4], inside the frame, drawn by the caller) and therefore its own resample taps, which are built ON THE DEVICE in the
+ * double arithmetic of Resample.c (two small launches), followed by the horizontal and the vertical pass.  bicubic = 0 uses the
+ * bilinear filter.  workspace: pm_aug_resized_crop_workspace_bytes(B, Hs, Ws, out) bytes, 16-byte aligned. */
+size_t pm_aug_resized_crop_workspace_bytes(int B, int Hs, int Ws, int out);
+int pm_aug_resized_crop_u8(const unsigned char* src, const int* box, unsigned char* dst, int bicubic, int B, int Hs, int Ws, int out,
+                           void* workspace, size_t ws_bytes, void* stream);
+
 /* ColorJitter: per sample, ops in `order` (0 brightness, 1 contrast, 2 saturation, 3 hue; -1 = none): ImageEnhance blends (float32,
  * truncating / clipping as Blend.c), contrast against int(mean luminance + 0.5) of the image as it stands before that op, hue as
  * an HSV round trip with H += hue_shift (uint8 wrap-around; hue_shift = uint8(hue_factor * 255)).  lsum: u64 [B] scratch.

@@ -29,11 +29,24 @@ PRECISION_BITS = 32 - 8 - 2   # Resample.c
 # ---------------------------------------------------------------------------------------------------------------------
 # Resize: Pillow ImagingResample, bilinear (triangle) filter with antialiasing, 8 bits per channel
 # ---------------------------------------------------------------------------------------------------------------------
-def _resample_coeffs(in_size: int, out_size: int):
-    """Resample.c precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter (support 1.0) over the whole input."""
+def _bicubic(x: float) -> float:
+    """Resample.c bicubic_filter (a = -0.5), double arithmetic."""
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def _resample_coeffs(in_size: int, out_size: int, filt: str = "bilinear"):
+    """Resample.c precompute_coeffs + normalize_coeffs_8bpc over the whole input: bilinear (triangle, support 1) or bicubic
+    (support 2)."""
     scale = in_size / out_size
     filterscale = max(scale, 1.0)
-    support = 1.0 * filterscale
+    support = (1.0 if filt == "bilinear" else 2.0) * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((out_size, 2), dtype=np.int64)
     kk = np.zeros((out_size, ksize), dtype=np.float64)
@@ -50,7 +63,7 @@ def _resample_coeffs(in_size: int, out_size: int):
         xmax -= xmin
         for x in range(xmax):
             a = (x + xmin - center + 0.5) * ss
-            w = 1.0 - abs(a) if abs(a) < 1.0 else 0.0
+            w = (1.0 - abs(a) if abs(a) < 1.0 else 0.0) if filt == "bilinear" else _bicubic(a)
             kk[xx, x] = w
             ww += w
         for x in range(xmax):
@@ -66,13 +79,23 @@ def _clip8(ss: np.ndarray) -> np.ndarray:
     return np.clip(ss >> PRECISION_BITS, 0, 255).astype(np.uint8)
 
 
+def resized_crop(frames: np.ndarray, boxes, out_h: int, out_w: int, filt: str = "bicubic") -> np.ndarray:
+    """torchvision functional.resized_crop on PIL images: img.crop((left, top, left + w, top + h)).resize((out_w, out_h), filt),
+    per sample.  boxes: [B][4] = (top, left, h, w).  (main_pretrain.py:157: RandomResizedCrop(224, scale=(0.2, 1), bicubic).)"""
+    return np.concatenate([resize(frames[b:b + 1, t:t + h, l:l + w], out_h, out_w, filt) for b, (t, l, h, w) in enumerate(boxes)])
+
+
 def resize_bilinear(frames: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    return resize(frames, out_h, out_w, "bilinear")
+
+
+def resize(frames: np.ndarray, out_h: int, out_w: int, filt: str = "bilinear") -> np.ndarray:
     """uint8 [B, H, W, C] -> uint8 [B, out_h, out_w, C]: horizontal pass, then vertical pass, each rounded to uint8
     (ImagingResampleInner: a pass is skipped when the size does not change)."""
     x = frames
     B, H, W, C = x.shape
     if out_w != W:
-        bounds, ik, _ = _resample_coeffs(W, out_w)
+        bounds, ik, _ = _resample_coeffs(W, out_w, filt)
         out = np.empty((B, H, out_w, C), dtype=np.uint8)
         xi = x.astype(np.int64)
         for xx in range(out_w):
@@ -81,7 +104,7 @@ def resize_bilinear(frames: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
             out[:, :, xx, :] = _clip8(ss)
         x = out
     if out_h != H:
-        bounds, ik, _ = _resample_coeffs(H, out_h)
+        bounds, ik, _ = _resample_coeffs(H, out_h, filt)
         out = np.empty((B, out_h, x.shape[2], C), dtype=np.uint8)
         xi = x.astype(np.int64)
         for yy in range(out_h):

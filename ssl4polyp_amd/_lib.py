@@ -45,6 +45,7 @@ SIGNATURES = {
     "pm_cast": [P, P, I, L, P],
     "pm_preprocess_u8": [P, P, P, I, I, I, F, F, F, F, F, F, P],
     "pm_aug_resize_u8": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],
+    "pm_aug_resized_crop_u8": [P, P, P, I, I, I, I, I, P, ctypes.c_size_t, P],
     "pm_aug_color_jitter_u8": [P, P, P, P, I, I, I, P],
     "pm_aug_gaussian_blur_u8": [P, P, P, P, I, I, I, I, P],
     "pm_aug_geometry_u8": [P, P, P, I, I, I, I, F, F, F, F, F, F, P],
@@ -126,6 +127,8 @@ def load():
     lib.pm_gemm_workspace_bytes.argtypes = [I, I, I, I, I, I, P]
     lib.pm_workspace_bytes.restype = ctypes.c_size_t
     lib.pm_workspace_bytes.argtypes = [I, I, I]
+    lib.pm_aug_resized_crop_workspace_bytes.restype = ctypes.c_size_t
+    lib.pm_aug_resized_crop_workspace_bytes.argtypes = [I, I, I, I]
     lib.pm_wgrad_group_workspace_bytes.restype = ctypes.c_size_t
     lib.pm_wgrad_group_workspace_bytes.argtypes = [P, I, I, I]
     for name, argtypes in SIGNATURES.items():

@@ -59,6 +59,90 @@ __global__ __launch_bounds__(256) void resample_kernel(const unsigned char* __re
   }
 }
 
+// Per-sample taps on the device: Resample.c precompute_coeffs + normalize_coeffs_8bpc in the C source's double arithmetic, one
+// thread per (sample, output index).  RandomResizedCrop gives every sample its own crop size, i.e. its own scale and taps; the
+// two tables of a batch (B x 224 x <= 17 taps) are built here instead of 2 x B Python loops on the host.
+__device__ __forceinline__ double resample_filter(double x, int bicubic) {
+  if (x < 0.0) x = -x;
+  if (!bicubic) return x < 1.0 ? 1.0 - x : 0.0;
+  const double a = -0.5;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+
+// box[b] = (top, left, h, w); axis 0: in_size = w (horizontal taps), axis 1: in_size = h
+__global__ __launch_bounds__(256) void resample_coeffs_kernel(const int* __restrict__ box, int axis, int out_size, int bicubic,
+                                                              int ksize_max, int* __restrict__ bounds, int* __restrict__ taps,
+                                                              int B) {
+  const int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= B * out_size) return;
+  const int b = id / out_size, xx = id % out_size;
+  const int in_size = box[4 * b + (axis ? 2 : 3)];
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = (bicubic ? 2.0 : 1.0) * filterscale;
+  const double center = (xx + 0.5) * scale;
+  const double ss = 1.0 / filterscale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  if (xmax > ksize_max) xmax = ksize_max;  // (cannot happen when the caller sized ksize_max from the largest crop)
+  double ww = 0.0;
+  for (int x = 0; x < xmax; ++x) ww += resample_filter((x + xmin - center + 0.5) * ss, bicubic);
+  int* k = taps + (long)id * ksize_max;
+  for (int x = 0; x < ksize_max; ++x) {
+    int v = 0;
+    if (x < xmax) {
+      double w = resample_filter((x + xmin - center + 0.5) * ss, bicubic);
+      if (ww != 0.0) w /= ww;
+      v = w < 0 ? (int)(-0.5 + w * (double)(1 << kPrecisionBits)) : (int)(0.5 + w * (double)(1 << kPrecisionBits));
+    }
+    k[x] = v;
+  }
+  bounds[2 * id] = xmin;
+  bounds[2 * id + 1] = xmax;
+}
+
+// one pass of the cropped resize with per-sample tables: horizontal (rows top .. top + h of src -> tmp rows 0 .. h) or vertical
+// (tmp rows -> dst)
+__global__ __launch_bounds__(256) void resample_crop_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                            const int* __restrict__ box, const int* __restrict__ bounds,
+                                                            const int* __restrict__ taps, int ksize, int B, int Hs, int Ws,
+                                                            int Hd, int Wd, int out_size, int vertical) {
+  // horizontal: src [B][Hs][Ws], dst = tmp [B][Hd = Hs][Wd = out]; vertical: src = tmp [B][Hs][Ws = out], dst [B][Hd = out][Wd = out]
+  const long total = (long)B * Hd * Wd;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long)gridDim.x * 256) {
+    const int xo = id % Wd;
+    const int yo = (id / Wd) % Hd;
+    const int b = id / ((long)Wd * Hd);
+    const int top = box[4 * b], left = box[4 * b + 1], h = box[4 * b + 2];
+    if (!vertical && yo >= h) continue;  // rows below the crop are never read
+    const int o = vertical ? yo : xo;
+    const long ti = (long)b * out_size + o;
+    const int lo = bounds[2 * ti], n = bounds[2 * ti + 1];
+    const int* k = taps + ti * ksize;
+    int ss0 = 1 << (kPrecisionBits - 1), ss1 = ss0, ss2 = ss0;
+    const unsigned char* p = vertical ? src + (((long)b * Hs + lo) * Ws + xo) * 3
+                                      : src + (((long)b * Hs + top + yo) * Ws + left + lo) * 3;
+    const long step = vertical ? (long)Ws * 3 : 3;
+    for (int t = 0; t < n; ++t) {
+      const int kk = k[t];
+      ss0 += p[0] * kk;
+      ss1 += p[1] * kk;
+      ss2 += p[2] * kk;
+      p += step;
+    }
+    unsigned char* q = dst + (((long)b * Hd + yo) * Wd + xo) * 3;
+    ss0 >>= kPrecisionBits; ss1 >>= kPrecisionBits; ss2 >>= kPrecisionBits;
+    q[0] = (unsigned char)(ss0 < 0 ? 0 : (ss0 > 255 ? 255 : ss0));
+    q[1] = (unsigned char)(ss1 < 0 ? 0 : (ss1 > 255 ? 255 : ss1));
+    q[2] = (unsigned char)(ss2 < 0 ? 0 : (ss2 > 255 ? 255 : ss2));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // ColorJitter: four per-pixel ops in a per-sample order; contrast needs the image's mean luminance first
 // ---------------------------------------------------------------------------------------------
@@ -309,6 +393,37 @@ extern "C" int pm_aug_resize_u8(const unsigned char* src, unsigned char* tmp, un
   if (do_y)
     hipLaunchKernelGGL(resample_kernel, dim3(aug_grid((long)B * Ho * Wo)), dim3(256), 0, s, cur, dst, bounds_y, taps_y, ksize_y, B,
                        Hs, Wo, Ho, Wo, 1);
+  return pm_check_launch();
+}
+
+extern "C" size_t pm_aug_resized_crop_workspace_bytes(int B, int Hs, int Ws, int out) {
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || out <= 0) return 0;
+  const int big = Hs > Ws ? Hs : Ws;
+  const int ksize = (int)((2.0 * big) / out + 1.0) * 2 + 3;   // >= ceil(2 * scale) * 2 + 1 for every crop inside the frame
+  const size_t tables = 2 * ((size_t)B * out * 2 + (size_t)B * out * ksize) * sizeof(int);
+  return tables + (size_t)B * Hs * out * 3 + 256;
+}
+
+extern "C" int pm_aug_resized_crop_u8(const unsigned char* src, const int* box, unsigned char* dst, int bicubic, int B, int Hs, int Ws,
+                                      int out, void* workspace, size_t ws_bytes, void* stream) {
+  if (!src || !box || !dst || !workspace) return PM_EINVAL;
+  if (B <= 0 || Hs <= 0 || Ws <= 0 || out <= 0) return PM_ESHAPE;
+  if (ws_bytes < pm_aug_resized_crop_workspace_bytes(B, Hs, Ws, out) || ((uintptr_t)workspace & 15)) return PM_EINVAL;
+  const int big = Hs > Ws ? Hs : Ws;
+  const int ksize = (int)((2.0 * big) / out + 1.0) * 2 + 3;
+  int* bounds_x = reinterpret_cast<int*>(workspace);
+  int* taps_x = bounds_x + (size_t)B * out * 2;
+  int* bounds_y = taps_x + (size_t)B * out * ksize;
+  int* taps_y = bounds_y + (size_t)B * out * 2;
+  unsigned char* tmp = reinterpret_cast<unsigned char*>(taps_y + (size_t)B * out * ksize);
+  hipStream_t s = pm_stream(stream);
+  const int gc = (B * out + 255) / 256;
+  hipLaunchKernelGGL(resample_coeffs_kernel, dim3(gc), dim3(256), 0, s, box, 0, out, bicubic ? 1 : 0, ksize, bounds_x, taps_x, B);
+  hipLaunchKernelGGL(resample_coeffs_kernel, dim3(gc), dim3(256), 0, s, box, 1, out, bicubic ? 1 : 0, ksize, bounds_y, taps_y, B);
+  hipLaunchKernelGGL(resample_crop_kernel, dim3(aug_grid((long)B * Hs * out)), dim3(256), 0, s, src, tmp, box, bounds_x, taps_x, ksize,
+                     B, Hs, Ws, Hs, out, out, 0);
+  hipLaunchKernelGGL(resample_crop_kernel, dim3(aug_grid((long)B * out * out)), dim3(256), 0, s, tmp, dst, box, bounds_y, taps_y, ksize,
+                     B, Hs, out, out, out, out, 1);
   return pm_check_launch();
 }
 

@@ -125,6 +125,43 @@ def draw_train_params(B: int, generator: Optional[torch.Generator] = None, brigh
             "angle": u(-degrees, degrees).numpy()}
 
 
+def draw_rrc_boxes(B: int, height: int, width: int, generator: Optional[torch.Generator] = None, scale=(0.2, 1.0),
+                   ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    """torchvision 0.10 RandomResizedCrop.get_params for B frames of one size -> int32 [B, 4] = (top, left, h, w)
+    (mae/main_pretrain.py:157: scale (0.2, 1.0), default ratio): up to ten tries of area ~ U(scale) x aspect ~ logU(ratio), then
+    the central-crop fallback."""
+    import math
+
+    import numpy as np
+    g = generator
+    area = height * width
+    lr0, lr1 = math.log(ratio[0]), math.log(ratio[1])
+    out = np.zeros((B, 4), dtype=np.int32)
+    for b in range(B):
+        for _ in range(10):
+            target = area * torch.empty(1).uniform_(scale[0], scale[1], generator=g).item()
+            aspect = math.exp(torch.empty(1).uniform_(lr0, lr1, generator=g).item())
+            w = int(round(math.sqrt(target * aspect)))
+            h = int(round(math.sqrt(target / aspect)))
+            if 0 < w <= width and 0 < h <= height:
+                i = torch.randint(0, height - h + 1, (1,), generator=g).item()
+                j = torch.randint(0, width - w + 1, (1,), generator=g).item()
+                out[b] = (i, j, h, w)
+                break
+        else:
+            in_ratio = width / height
+            if in_ratio < min(ratio):
+                w = width
+                h = int(round(w / min(ratio)))
+            elif in_ratio > max(ratio):
+                h = height
+                w = int(round(h * max(ratio)))
+            else:
+                w, h = width, height
+            out[b] = ((height - h) // 2, (width - w) // 2, h, w)
+    return out
+
+
 class DeviceAugmenter:
     """The reference's whole train transform after decoding, on the device: [Resize ->] ColorJitter -> GaussianBlur(25) -> flips
     -> RandomRotation(180) -> ToTensor -> Normalize, six launches over a uint8 batch (pm_aug_*), f32 NCHW out.  The host does
@@ -182,6 +219,42 @@ class DeviceAugmenter:
                                         by.data_ptr(), ty.data_ptr(), ky, B, Hs, Ws, S, S,
                                         torch.cuda.current_stream(self.device).cuda_stream), "pm_aug_resize_u8")
         return out
+
+    def random_resized_crop(self, frames: torch.Tensor, boxes=None, generator: Optional[torch.Generator] = None,
+                            bicubic: bool = True) -> torch.Tensor:
+        """uint8 [B, Hs, Ws, 3] -> uint8 [B, size, size, 3]: RandomResizedCrop(size, scale=(0.2, 1.0), interpolation=bicubic) of
+        the MAE pre-train transform (main_pretrain.py:157), one crop box per sample (drawn here unless given)."""
+        import numpy as np
+        if frames.dtype != torch.uint8 or frames.ndim != 4 or frames.shape[-1] != 3 or not frames.is_contiguous() or not frames.is_cuda:
+            raise ValueError("frames must be a contiguous uint8 [B, H, W, 3] tensor on the GPU")
+        B, Hs, Ws, _ = frames.shape
+        S = self.size
+        if boxes is None:
+            boxes = draw_rrc_boxes(B, Hs, Ws, generator)
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32)
+        if boxes.shape != (B, 4) or (boxes[:, 2:] <= 0).any() or (boxes[:, :2] < 0).any() or \
+                (boxes[:, 0] + boxes[:, 2] > Hs).any() or (boxes[:, 1] + boxes[:, 3] > Ws).any():
+            raise ValueError("crop boxes must be (top, left, h, w) inside the frame, one per sample")
+        lib = _lib.load()
+        need = int(lib.pm_aug_resized_crop_workspace_bytes(B, Hs, Ws, S))
+        ws = self._buf("rrc_ws", (need,), torch.uint8)
+        box_d = self._upload("rrc_box", boxes)
+        out = self._buf("rrc_out", (B, S, S, 3), torch.uint8)
+        _lib.check(lib.pm_aug_resized_crop_u8(frames.data_ptr(), box_d.data_ptr(), out.data_ptr(), 1 if bicubic else 0, B, Hs, Ws, S,
+                                              ws.data_ptr(), ws.numel(), torch.cuda.current_stream(self.device).cuda_stream),
+                   "pm_aug_resized_crop_u8")
+        return out
+
+    def mae_transform(self, frames: torch.Tensor, boxes=None, hflip=None, generator: Optional[torch.Generator] = None,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The MAE pre-train transform after decoding (main_pretrain.py:156-160): RandomResizedCrop(bicubic) -> RandomHorizontalFlip
+        -> ToTensor -> Normalize, f32 [B, 3, size, size]."""
+        B = frames.shape[0]
+        x = self.random_resized_crop(frames, boxes, generator)
+        if hflip is None:
+            hflip = (torch.rand(B, generator=generator) < 0.5)
+        flips = self._upload("mae_flips", torch.as_tensor(hflip).to(torch.uint8).numpy())
+        return preprocess_u8(x, flips, self.mean, self.std, out=out)
 
     def __call__(self, frames: torch.Tensor, params: Optional[dict] = None, generator: Optional[torch.Generator] = None,
                  to_f32: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -6,7 +6,8 @@ torchvision 0.10 transforms end up in for PIL images (classification/data/transf
 
 torchvision's PIL paths are thin wrappers (functional_pil.py): resize -> Image.resize(BILINEAR); adjust_brightness / contrast /
 saturation -> ImageEnhance.{Brightness, Contrast, Color}.enhance; adjust_hue -> HSV split, uint8 add on H, merge, convert;
-rotate -> Image.rotate(angle, NEAREST, expand=False, center=None, fillcolor=0).  Each is called here exactly like that and the
+rotate -> Image.rotate(angle, NEAREST, expand=False, center=None, fillcolor=0); resized_crop (RandomResizedCrop of
+mae/main_pretrain.py:157) -> Image.crop(box).resize(size, BICUBIC).  Each is called here exactly like that and the
 uint8 result stored beside its input and parameters (tests/golden/augment.npz, ~250 KB).  GaussianBlur is torchvision tensor
 code (no Pillow routine behind it) and therefore has no vector here: that stage stays parity-unpinned.
 """
@@ -51,6 +52,10 @@ def main():
         a = frame(h, w, 10 + h, 15.0)
         out[f"resize_in/{h}x{w}"] = a
         out[f"resize/{h}x{w}->{oh}x{ow}"] = np.asarray(Image.fromarray(a).resize((ow, oh), Image.BILINEAR))
+    a = frame(150, 200, 77, 15.0)
+    out["rrc_in"] = a
+    for (t, l, h, w) in ((0, 0, 150, 200), (20, 30, 100, 120), (100, 150, 40, 37), (3, 5, 56, 56)):
+        out[f"rrc/{t},{l},{h},{w}"] = np.asarray(Image.fromarray(a).crop((l, t, l + w, t + h)).resize((56, 56), Image.BICUBIC))
     path = os.path.join(HERE, "augment.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB (Pillow {PIL.__version__})")

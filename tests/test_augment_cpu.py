@@ -24,6 +24,9 @@ def test_oracle_equals_pillow_vectors(golden):
             src, dst = parts[1].split("->")
             oh, ow = (int(v) for v in dst.split("x"))
             got = R.resize_bilinear(fx["resize_in/" + src][None], oh, ow)[0]
+        elif parts[0] == "rrc":
+            box = tuple(int(v) for v in parts[1].split(","))
+            got = R.resized_crop(fx["rrc_in"][None], [box], 56, 56, "bicubic")[0]
         else:
             continue
         assert got.dtype == np.uint8 and np.array_equal(got, want), key

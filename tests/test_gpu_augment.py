@@ -148,3 +148,28 @@ def test_device_prefetcher_with_augmenter_feeds_a_model():
     assert all(torch.equal(x[0], y[0]) for x, y in zip(a, b)) and not torch.equal(a[0][0], c[0][0])
     m = A.ViT_from_MAE(None, True, 2, False, None, embed_dim=64, depth=1, num_heads=2, out_token="cls").to(DEV)
     assert m(a[0][0]).shape == (3, 2)
+
+
+@pytest.mark.parametrize("Hs,Ws", [(576, 720), (224, 224), (150, 333)])
+def test_random_resized_crop_bicubic_bit_exact(Hs, Ws):
+    """RandomResizedCrop(224, scale=(0.2, 1), bicubic) of the MAE pre-train transform (main_pretrain.py:157): per-sample crop
+    boxes -> per-sample resample taps built ON THE DEVICE in double -> two passes; equals oracle.resized_crop (= Pillow's
+    crop + resize(BICUBIC), pinned in tests/test_augment_cpu.py) bit for bit.  Then flip + ToTensor + Normalize."""
+    from oracle import augment_ref as R
+    from oracle.input_ref import to_tensor_normalize
+    from ssl4polyp_amd.data import DeviceAugmenter, draw_rrc_boxes
+    B = 7
+    x = _frames(B, Hs, Ws, 31)
+    boxes = draw_rrc_boxes(B, Hs, Ws, torch.Generator().manual_seed(2))
+    boxes[0] = (0, 0, Hs, Ws)                                  # the whole frame
+    boxes[1] = (Hs - 17, Ws - 23, 17, 23)                      # a small corner crop: strong upscaling
+    assert (boxes[:, 2] > 0).all() and (boxes[:, 0] + boxes[:, 2] <= Hs).all() and (boxes[:, 1] + boxes[:, 3] <= Ws).all()
+    aug = DeviceAugmenter(DEV, size=224)
+    got = aug.random_resized_crop(torch.from_numpy(x).to(DEV), boxes).cpu().numpy()
+    want = R.resized_crop(x, boxes, 224, 224, "bicubic")
+    assert np.array_equal(got, want)
+    got_bl = aug.random_resized_crop(torch.from_numpy(x).to(DEV), boxes, bicubic=False).cpu().numpy()
+    assert np.array_equal(got_bl, R.resized_crop(x, boxes, 224, 224, "bilinear"))
+    hflip = torch.tensor([1, 0, 1, 1, 0, 0, 1], dtype=torch.bool)
+    t = aug.mae_transform(torch.from_numpy(x).to(DEV), boxes, hflip)
+    assert torch.equal(t.cpu(), to_tensor_normalize(torch.from_numpy(want), hflip.to(torch.uint8)))
