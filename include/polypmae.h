@@ -396,6 +396,22 @@ enum pm_ws_kind { PM_WS_LAYERNORM_BWD = 1, PM_WS_COLSUM = 2, PM_WS_GEMM_COLSUM =
 size_t pm_gemm_workspace_bytes(int a_kmajor, int b_kmajor, int in_dtype, int M, int N, int K, const pm_gemm_opts* opts);
 size_t pm_workspace_bytes(int kind, int M, int N);
 
+/* ---- gradient exchange for hosts without torch.distributed (SURVEY 8-b `pm_comm_*`) --------------------------------------
+ * A handle over RCCL (bound at run time: PM_EARCH when no librccl can be loaded).  Replaces DistributedDataParallel's reducer of
+ * the reference (mae/main_pretrain.py:212-214, train_classification.py:5746-5750) for a C / C++ host; the Python host does the
+ * same through torch.distributed (parallel.GradSync).  One process per GPU: rank 0 calls pm_comm_unique_id and hands the 128
+ * bytes to the other ranks out of band (file, socket, environment); every rank then calls pm_comm_create on ITS device.
+ * pm_comm_allreduce_f32 sums, in place, n_buckets slices base[lo[i] .. hi[i]) (element offsets) of one f32 range over all ranks
+ * in one RCCL group on `stream` -- the flat gradient range needs no packing, a bucket is a slice; the caller orders `stream`
+ * against its compute stream with events and divides by the world size where it consumes the sums (pm_adamw_dev grad_scale).
+ * The handle is the one object this library creates; pm_comm_destroy frees it. */
+typedef struct pm_comm pm_comm;
+int pm_comm_unique_id(void* id128);
+int pm_comm_create(pm_comm** out, const void* id128, int rank, int world);
+int pm_comm_world(const pm_comm* c, int* rank, int* world);
+int pm_comm_allreduce_f32(pm_comm* c, float* base, const long* lo, const long* hi, int n_buckets, void* stream);
+int pm_comm_destroy(pm_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

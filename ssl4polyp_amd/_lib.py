@@ -49,6 +49,11 @@ SIGNATURES = {
     "pm_aug_color_jitter_u8": [P, P, P, P, I, I, I, P],
     "pm_aug_gaussian_blur_u8": [P, P, P, P, I, I, I, I, P],
     "pm_aug_geometry_u8": [P, P, P, I, I, I, I, F, F, F, F, F, F, P],
+    "pm_comm_unique_id": [P],
+    "pm_comm_create": [P, P, I, I],
+    "pm_comm_world": [P, P, P],
+    "pm_comm_allreduce_f32": [P, P, P, P, I, P],
+    "pm_comm_destroy": [P],
     "pm_vit_head_fwd": [P, I, I, P, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "pm_vit_head_bwd": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, P, P, P, P, I, I, I, P],
     "pm_supervised_loss_fwd": [P, P, P, P, P, P, I, I, P],
@@ -61,7 +66,7 @@ SIGNATURES = {
     "pm_grad_stats": [P, L, P, P],
 }
 
-ABI_VERSION = 7  # pm_abi_version() of the library these signatures describe
+ABI_VERSION = 8  # pm_abi_version() of the library these signatures describe
 
 WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4
 

@@ -170,3 +170,52 @@ def test_rccl_world1_forced_sync_matches_unsynchronised_run():
     # fence between the RCCL stream, the wgrad side stream, the overlapped AdamW and the next forward would show here
     assert same and la == lb
     assert sent[0] == sent[1] == 4 * (128 + 64) and sent[1] < sent[2] == sent[3] < sent[4] == sent[5], sent
+
+
+def _pm_comm_worker(q):
+    """pm_comm_* (C-ABI over RCCL, include/polypmae.h) at world size 1 on cuda:0: id -> create -> bucketed in-place SUM on a side
+    stream -> destroy.  A one-rank SUM is the identity; what is exercised is the binding (dlopen of RCCL, the handle, the group
+    call, stream semantics)."""
+    import ctypes
+    try:
+        from ssl4polyp_amd import _lib
+        lib = _lib.load()
+        torch.cuda.set_device(0)
+        idb = ctypes.create_string_buffer(128)
+        st = lib.pm_comm_unique_id(idb)
+        if st != 0:
+            q.put(("no-rccl", st))
+            return
+        comm = ctypes.c_void_p()
+        _lib.check(lib.pm_comm_create(ctypes.byref(comm), idb, 0, 1), "pm_comm_create")
+        rank, world = ctypes.c_int(-1), ctypes.c_int(-1)
+        _lib.check(lib.pm_comm_world(comm, ctypes.byref(rank), ctypes.byref(world)), "pm_comm_world")
+        g = torch.randn(1 << 20, device="cuda")
+        want = g.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        lo = (ctypes.c_long * 3)(0, 4096, 600000)
+        hi = (ctypes.c_long * 3)(4096, 600000, 1 << 20)
+        _lib.check(lib.pm_comm_allreduce_f32(comm, g.data_ptr(), lo, hi, 3, side.cuda_stream), "pm_comm_allreduce_f32")
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        bad_args = lib.pm_comm_allreduce_f32(comm, g.data_ptr(), lo, hi, 0, side.cuda_stream)
+        _lib.check(lib.pm_comm_destroy(comm), "pm_comm_destroy")
+        q.put(("ok", bool(torch.equal(g, want)), rank.value, world.value, bad_args))
+    except Exception as e:  # pragma: no cover
+        q.put(("error", repr(e)))
+
+
+def test_pm_comm_c_abi_world1():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_pm_comm_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    if res[0] == "no-rccl":
+        pytest.skip(f"no loadable RCCL on this box (status {res[1]})")
+    assert res[0] == "ok", res
+    _, same, rank, world, bad = res
+    assert same and rank == 0 and world == 1 and bad != 0
