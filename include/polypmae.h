@@ -171,6 +171,10 @@ int pm_assemble_tokens_bwd(const float* dx, const int* ids_keep, void* demb, int
 
 /* MAE random masking from noise (models_mae.py:123-148): stable ascending argsort per sample.
  * noise f32 [B,L]; ids_shuffle/ids_restore int32 [B,L]; mask f32 [B,L] (1 = removed). L <= 1024. */
+/* Masking noise for random_masking (models_mae.py:132 `torch.rand(N, L, device=x.device)`): noise[i] = U[0, 1) with 24 random bits,
+ * Philox4x32-10 keyed by `seed`, counter = (i / 4, stream_id) -- a pure function of (seed, stream_id, i), whatever the launch
+ * geometry, device or rank layout.  The caller advances stream_id per draw (per forward pass). */
+int pm_mae_noise(float* noise, long n, unsigned long long seed, unsigned int stream_id, void* stream);
 int pm_mae_masking(const float* noise, int* ids_shuffle, int* ids_restore, float* mask, int B, int L, int len_keep,
                    void* stream);
 

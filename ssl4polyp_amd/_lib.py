@@ -36,6 +36,7 @@ SIGNATURES = {
     "pm_patch_im2col": [P, P, P, I, I, I, I, I, I, P],
     "pm_assemble_tokens": [P, P, P, P, P, I, I, I, P],
     "pm_assemble_tokens_bwd": [P, P, P, I, P, P, I, I, I, P],
+    "pm_mae_noise": [P, L, ctypes.c_ulonglong, ctypes.c_uint, P],
     "pm_mae_masking": [P, P, P, P, I, I, I, P],
     "pm_mae_unshuffle": [P, P, P, P, P, I, I, I, I, P],
     "pm_mae_unshuffle_bwd": [P, P, P, I, P, I, I, I, I, P, ctypes.c_size_t, P],

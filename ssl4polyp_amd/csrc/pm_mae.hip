@@ -31,6 +31,34 @@ __global__ __launch_bounds__(256) void masking_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// masking noise: counter-based U[0, 1) (Philox4x32-10, Salmon et al. SC'11), one 128-bit block per 4 values
+//   key = (seed_lo, seed_hi), counter = (element index / 4, stream, 0, 0); value = (x >> 8) * 2^-24: 24 random bits, like torch.rand
+// The reference draws torch.rand(N, L, device=x.device) (models_mae.py:132): a device generator whose stream no other device
+// or library version reproduces.  A counter-based generator makes the noise a pure function of (seed, stream, index): the same
+// on every run, rank layout and launch geometry, and it needs no ATen launch.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+    c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ __launch_bounds__(256) void noise_kernel(float* __restrict__ out, long n, unsigned long long seed, unsigned stream_id) {
+  const long nq = (n + 3) >> 2;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    unsigned c[4] = {(unsigned)q, (unsigned)(q >> 32), stream_id, 0u};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * q + e < n) out[4 * q + e] = (float)(c[e] >> 8) * 0x1p-24f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // decoder input: out[b,0] = emb[b,0] + dpos[0];
 //                out[b,1+i] = (r = ids_restore[b,i]) < keep ? emb[b,1+r] : mask_token;  + dpos[1+i]
 // ---------------------------------------------------------------------------------------------
@@ -275,6 +303,15 @@ inline int cap_grid(long work_items, int per_block, int cap) {
 }
 
 }  // namespace
+
+extern "C" int pm_mae_noise(float* noise, long n, unsigned long long seed, unsigned int stream_id, void* stream) {
+  if (!noise) return PM_EINVAL;
+  if (n <= 0) return PM_ESHAPE;
+  long g = ((n + 3) / 4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(noise_kernel, dim3((int)g), dim3(256), 0, pm_stream(stream), noise, n, seed, stream_id);
+  return pm_check_launch();
+}
 
 extern "C" int pm_mae_masking(const float* noise, int* ids_shuffle, int* ids_restore, float* mask, int B, int L,
                               int len_keep, void* stream) {

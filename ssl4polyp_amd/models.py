@@ -634,13 +634,28 @@ class MaskedAutoencoderViT(nn.Module):
         x = torch.einsum("nhwpqc->nchpwq", x)
         return x.reshape(shape=(x.shape[0], 3, h * p, h * p))
 
+    def _draw_noise(self, B: int, device) -> torch.Tensor:
+        """The masking noise of models_mae.py:132 (`torch.rand(N, L, device=x.device)`) from the library's counter-based generator
+        (pm_mae_noise: Philox4x32-10): key = torch's current seed (torch.manual_seed / torch.initial_seed, which every training
+        script of the reference sets per rank: main_pretrain.py:147 seed + rank), stream = the number of draws since that seed was
+        last seen.  A pure function of (seed, draw index, element): re-seeding replays the same masks, and no ATen kernel runs."""
+        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        st = self.__dict__.get("_noise_state")
+        if st is None or st[0] != seed:
+            st = self.__dict__["_noise_state"] = [seed, 0]
+        L = self.patch_embed.num_patches
+        noise = torch.empty(B, L, dtype=torch.float32, device=device)
+        _lib.check(self._rt.k.lib.pm_mae_noise(_ptr(noise), B * L, seed, st[1] & 0xFFFFFFFF, _stream()), "pm_mae_noise")
+        st[1] += 1
+        return noise
+
     def forward(self, imgs, mask_ratio=0.75, noise: Optional[torch.Tensor] = None):
-        """-> (loss, pred [N, L, p*p*3], mask [N, L]).  `noise` replaces torch.rand (models_mae.py:132) for tests."""
+        """-> (loss, pred [N, L, p*p*3], mask [N, L]).  `noise` replaces the generator's draw (tests; models_mae.py:132)."""
         rt = self._rt
         rt.ensure(imgs.device)
         assert imgs.shape[2] == self.patch_embed.img_size[0] and imgs.shape[3] == self.patch_embed.img_size[1]
         if noise is None:
-            noise = torch.rand(imgs.shape[0], self.patch_embed.num_patches, device=imgs.device)
+            noise = self._draw_noise(imgs.shape[0], imgs.device)
         from . import ops  # registers torch.ops.polypmae.* on first use
         return torch.ops.polypmae.mae_forward(imgs, noise, float(mask_ratio), ops.register_runtime(rt), list(rt.flat.params))
 

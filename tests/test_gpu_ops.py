@@ -678,3 +678,33 @@ def test_wgrad_group(K, dims):
     # shapes outside the grouped kernel are refused with PM_ESHAPE (the engine then takes the per-GEMM path)
     assert not k.can_group_wgrad(2048 + 8, dims) and not k.can_group_wgrad(1024, dims)
     assert not k.wgrad_group(items, 1024)
+
+
+def test_mae_noise_is_the_counter_based_generator_bit_for_bit():
+    """pm_mae_noise (Philox4x32-10, the noise of random_masking, models_mae.py:132) against oracle/noise_ref.py -- itself
+    pinned by Random123's known-answer vectors -- for odd sizes, 64-bit seeds and several streams; and the model-level contract:
+    re-seeding torch replays the same masks, consecutive forwards draw different ones."""
+    import numpy as np
+    from oracle.noise_ref import mae_noise
+    from ssl4polyp_amd import _lib
+    from ssl4polyp_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    for n, seed, sid in ((196 * 5, 0, 0), (1, 7, 3), (50177, 0xDEADBEEFCAFEF00D, 4000000000), (4096, 2 ** 63 + 5, 1)):
+        out = torch.full((n,), -1.0, device=DEV)
+        _lib.check(lib.pm_mae_noise(_ptr(out), n, seed, sid, _stream()), "pm_mae_noise")
+        assert np.array_equal(out.cpu().numpy(), mae_noise(n, seed, sid)), (n, seed, sid)
+    import ssl4polyp_amd as A
+    m = A.MaskedAutoencoderViT(img_size=32, patch_size=8, embed_dim=64, depth=1, num_heads=2, decoder_embed_dim=32, decoder_depth=1,
+                               decoder_num_heads=1, precision="fp32").to(DEV)
+    x = torch.randn(4, 3, 32, 32, device=DEV)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        a1, a2 = m(x)[2].clone(), m(x)[2].clone()
+        torch.manual_seed(5)
+        b1 = m(x)[2].clone()
+        torch.manual_seed(6)
+        c1 = m(x)[2].clone()
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2) and not torch.equal(a1, c1)
+    want = torch.from_numpy(mae_noise(4 * 16, 5, 0)).view(4, 16)
+    from oracle.vit_mae_ref import masking_from_noise
+    assert torch.equal(a1.cpu(), masking_from_noise(want, 0.75)[1])

@@ -156,3 +156,18 @@ def test_flat_storage_aliasing_cpu():
     # moving the module invalidates the binding
     m.to(torch.float64)
     assert not f.bound(torch.device("cpu"))
+
+
+def test_philox_restatement_against_random123_known_answers():
+    """oracle/noise_ref.py (the CPU restatement pm_mae_noise is checked against on the GPU) on the known-answer vectors of the
+    Random123 distribution (kat_vectors: philox4x32 10 rounds)."""
+    from oracle.noise_ref import mae_noise, philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10(ctr, key)
+        assert tuple(int(x) for x in got) == want
+    x = mae_noise(1000, 1234, 7)
+    assert x.dtype.name == "float32" and x.min() >= 0.0 and x.max() < 1.0 and abs(x.mean() - 0.5) < 0.05
+    assert not (mae_noise(1000, 1234, 8) == x).all() and (mae_noise(997, 1234, 7) == x[:997]).all()
