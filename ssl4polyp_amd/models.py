@@ -636,17 +636,23 @@ class MaskedAutoencoderViT(nn.Module):
 
     def _draw_noise(self, B: int, device) -> torch.Tensor:
         """The masking noise of models_mae.py:132 (`torch.rand(N, L, device=x.device)`) from the library's counter-based generator
-        (pm_mae_noise: Philox4x32-10): key = torch's current seed (torch.manual_seed / torch.initial_seed, which every training
-        script of the reference sets per rank: main_pretrain.py:147 seed + rank), stream = the number of draws since that seed was
-        last seen.  A pure function of (seed, draw index, element): re-seeding replays the same masks, and no ATen kernel runs."""
-        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        st = self.__dict__.get("_noise_state")
-        if st is None or st[0] != seed:
-            st = self.__dict__["_noise_state"] = [seed, 0]
+        (pm_mae_noise: Philox4x32-10), keyed like the draw it replaces: seed and running offset of torch's DEVICE generator
+        (what `torch.manual_seed` / main_pretrain.py:147 `seed + rank` set), and the offset is advanced by the numbers drawn, as
+        torch.rand would.  So the noise is a pure function of (seed, numbers drawn before on this device, element): re-seeding
+        replays the same masks, consecutive forwards differ, ranks differ by their seeds -- and no ATen kernel runs."""
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.PolypMaeError("MAE forward under stream capture: the masking draw would be baked into the graph (the same "
+                                     "masks at every replay) -- pass `noise=` from a buffer the caller refills between replays")
         L = self.patch_embed.num_patches
+        n = B * L
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        seed = int(gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        off = int(gen.get_offset())
+        gen.set_offset(off + 4 * ((n + 3) // 4))   # (multiples of 4, as the generator requires)
+        # the 64-bit offset picks the stream: low word = pm_mae_noise's stream id, high word folded into the key
+        key = (seed ^ ((off >> 32) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
         noise = torch.empty(B, L, dtype=torch.float32, device=device)
-        _lib.check(self._rt.k.lib.pm_mae_noise(_ptr(noise), B * L, seed, st[1] & 0xFFFFFFFF, _stream()), "pm_mae_noise")
-        st[1] += 1
+        _lib.check(self._rt.k.lib.pm_mae_noise(_ptr(noise), n, key, off & 0xFFFFFFFF, _stream()), "pm_mae_noise")
         return noise
 
     def forward(self, imgs, mask_ratio=0.75, noise: Optional[torch.Tensor] = None):

@@ -705,6 +705,6 @@ def test_mae_noise_is_the_counter_based_generator_bit_for_bit():
         torch.manual_seed(6)
         c1 = m(x)[2].clone()
     assert torch.equal(a1, b1) and not torch.equal(a1, a2) and not torch.equal(a1, c1)
-    want = torch.from_numpy(mae_noise(4 * 16, 5, 0)).view(4, 16)
+    want = torch.from_numpy(mae_noise(4 * 16, 5, 0)).view(4, 16)   # seed 5, device-generator offset 0 right after the re-seed
     from oracle.vit_mae_ref import masking_from_noise
     assert torch.equal(a1.cpu(), masking_from_noise(want, 0.75)[1])
