@@ -33,6 +33,7 @@
 // Roofline: MFMA-bound; algorithmic FLOPs 2*M*N*K.
 #include "pm_common.h"
 #include <type_traits>
+#include <stdio.h>
 
 namespace {
 
@@ -1370,6 +1371,18 @@ extern "C" int pm_gemm_ws(const void* A, long lda, int a_kmajor, const void* B, 
 
 namespace {
 
+// tuning hook, read once: PM_CFG_CLASS="<nt_store>,<nt_gelu>,<nt_residual>,<nn_store>,<nn_dgelu>" forces a ring-kernel variant per
+// (operand layout, epilogue) class for in-step A/B runs (0 = the heuristics); unset in production
+const int* cfg_class_override() {
+  static int v[5] = {0, 0, 0, 0, 0};
+  static const bool init = [] {
+    const char* e = getenv("PM_CFG_CLASS");
+    if (e) sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+    return true;
+  }();
+  (void)init;
+  return v;
+}
 int tall_m() {  // tuning hook, read once: row count from which a problem counts as "tall" (see gemm_dispatch)
   static const int v = [] { const char* e = getenv("PM_TALL_M"); return e && e[0] ? atoi(e) : 20000; }();
   return v;
@@ -1450,9 +1463,17 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
         //    times and the direct register epilogue's strided 16-B stores cost more than the staging pass: software-pipelined
         //    loop + staged epilogue (cfg 24) for f32-residual and dgrad outputs (proj 59 vs 66 us, fc2 145 vs 147, dqkv 80 vs
         //    83, dproj 37.5 vs 38.5), ping-pong + staged (cfg 8) for the act-typed qkv (96 vs 102)
+        //  * plain dgrads (dfc1 / dproj / dqkv: N = 768): 256-row tiles with the staged epilogue (cfg 24) although the 192-row
+        //    direct kernel is faster ALONE (59-62 vs 65 us): in the step the chain runs beside the grouped weight gradients,
+        //    which hold 108 CUs -- 150 tiles of 256 rows + 108 = the chip, 198 tiles of 192 rows + 108 oversubscribe it and the
+        //    chain's third of a round queues behind the long weight-gradient workgroups (scratch/r3_exp8.sh, r3_exp9.sh:
+        //    +1.0 % cls in four same-box pairs, MAE +0.2 %)
         if (epilogue == PM_EPI_DGELU && !dgrad_pp()) cfg = 8;
+        else if (b_kmajor && !dgrad_pp()) cfg = 24;
         else if (M >= tall_m()) cfg = (epilogue == PM_EPI_STORE && !b_kmajor) ? 8 : 24;
       }
+      const int cls = !b_kmajor ? (epilogue == PM_EPI_GELU ? 1 : epilogue == PM_EPI_RESIDUAL ? 2 : 0) : (epilogue == PM_EPI_DGELU ? 4 : 3);
+      if (cfg_class_override()[cls]) cfg = cfg_class_override()[cls];
     }
     switch (cfg) {
       case 6: return launch_v3<256, 256, 2, 4, 4, 2, true>(a, b_kmajor, s);          // plain ring loop, register epilogue
