@@ -129,7 +129,8 @@ class Kernels:
             o = self._opts_cache = (key, _lib.GemmOpts(self.WGRAD_BLOCKS, self.gemm_variant), _lib.GemmOpts(0, self.gemm_variant))
         return o[1] if wgrad else o[2]
 
-    def gemm(self, A, lda, a_kmajor, B, ldb, b_kmajor, bias, C, ldc, epilogue, M, N, K, aux=None, resid=None, colsum=None):
+    def gemm(self, A, lda, a_kmajor, B, ldb, b_kmajor, bias, C, ldc, epilogue, M, N, K, aux=None, resid=None, colsum=None,
+             ws_name="_ws"):
         in_dtype = _lib.dtype_code(A.dtype)
         if _lib.dtype_code(B.dtype) != in_dtype:
             raise _lib.PolypMaeError("pm_gemm: operand dtypes differ")
@@ -145,7 +146,7 @@ class Kernels:
         if wgrad:
             need = self._need(("gemm", in_dtype, M, N, K, opts.max_blocks, opts.variant),
                               lambda: self.lib.pm_gemm_workspace_bytes(1, 1, in_dtype, M, N, K, ctypes.byref(opts)))
-            ws = self._scratch("_ws", need, A.device)
+            ws = self._scratch(ws_name, need, A.device)
         _lib.check(self.lib.pm_gemm_ex(_ptr(A), lda, int(a_kmajor), _ptr(B), ldb, int(b_kmajor), in_dtype, _ptr(bias),
                                        _ptr(C), ldc, _lib.dtype_code(C.dtype), epilogue, _ptr(aux), _ptr(resid), M, N, K,
                                        _ptr(ws), ws.numel() if ws is not None else 0, ctypes.byref(opts), _stream()), "pm_gemm")
@@ -158,6 +159,7 @@ class Kernels:
         """dx[M,K_in] = dy[M,N_out] @ W[N_out,K_in]  (W read as stored: k-major B operand); colsum += column sums of dx."""
         self.gemm(dy, N_out, 0, W, K_in, 1, None, dx, K_in, epilogue, M, K_in, N_out, aux=aux, colsum=colsum)
 
+    DEFER_JOIN = os.environ.get("PM_DEFER_JOIN", "1") != "0"    # A/B switch: the embedding's backward before the side-stream join
     BLOCK_CALLS = os.environ.get("PM_BLOCK_CALLS", "1") != "0"  # block forward as ONE C call (pm_vit_block_fwd) instead of seven
     GROUP_WGRAD = os.environ.get("PM_GROUP_WGRAD", "1") != "0"  # A/B switch: one grouped weight-gradient launch per block
     GROUP_BLOCKS = int(os.environ.get("PM_GROUP_BLOCKS", "0"))  # CUs the grouped launch may take (0 = one workgroup per tile)
@@ -214,9 +216,11 @@ class Kernels:
         cache[key] = ok
         return ok
 
-    def linear_wgrad(self, dy, x, dW, M, N_out, K_in, accumulate):
-        """dW[N_out,K_in] (+)= dy[M,N_out]^T @ x[M,K_in]  (both operands k-major, f32 output)."""
-        self.gemm(dy, N_out, 1, x, K_in, 1, None, dW, K_in, EPI_ACCUM if accumulate else EPI_STORE, N_out, K_in, M)
+    def linear_wgrad(self, dy, x, dW, M, N_out, K_in, accumulate, ws_name="_ws"):
+        """dW[N_out,K_in] (+)= dy[M,N_out]^T @ x[M,K_in]  (both operands k-major, f32 output).  ws_name: the split-K slab
+        scratch -- "_ws" belongs to the weight-gradient side stream; a launch on another stream that may run beside it names
+        its own."""
+        self.gemm(dy, N_out, 1, x, K_in, 1, None, dW, K_in, EPI_ACCUM if accumulate else EPI_STORE, N_out, K_in, M, ws_name=ws_name)
 
     def _colsum_workspace(self, device, M: int, N: int, fused: bool = False):
         # partial rows: one scratch per stream (main / wgrad side stream) so concurrent column sums never share it
@@ -431,13 +435,16 @@ class BlockStack:
                  last_bias_grad_done: bool, trainable: Sequence[bool], need_input_grad: bool,
                  accumulate: Callable[[str, int], bool], on_block_done: Optional[Callable[[int], None]] = None,
                  prev_bias_grad: Optional[torch.Tensor] = None,
-                 ends_pass: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+                 ends_pass: bool = True, defer_join: bool = False) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
         """dx / dx_act: gradient w.r.t. the stack output (f32 + act copy).  G[i][name] = f32 gradient
         tensors (vectors are += targets and must be zeroed or hold the running sum; matrices follow
         accumulate(name, i)).  `last_bias_grad_done`: the producer of dx already added colsum(dx) into the
         last block's fc2.bias gradient.  `prev_bias_grad`: bias gradient of the Linear that produced the
         stack input (receives colsum of the input gradient), if any.  `ends_pass`: nothing but a short tail follows this
         stack in the backward pass (the encoder; not the MAE decoder, whose weight gradients run beside the encoder's chain).
+        `defer_join`: do not make the main stream wait for the last blocks' weight gradients here -- the caller still has
+        main-stream work that does not read them (the embedding's backward) and calls `join_deferred(ws)` after it; the side
+        stream's last launches then run beside that work instead of in front of it.
         Returns (dx_in f32, dx_in act) or (None, None) when nothing below needs it."""
         k, g = self.k, self.g
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
@@ -574,5 +581,15 @@ class BlockStack:
             dx, dx_act = din, din_act
             if on_block_done is not None and not tr:
                 on_block_done(i)
-        join(0)
+        if defer_join:
+            ws._deferred_join = [pending.pop(j) for j in sorted(pending, reverse=True)]
+        else:
+            join(0)
         return dx, dx_act
+
+    @staticmethod
+    def join_deferred(ws: StackWorkspace) -> None:
+        """Make the current stream wait for the weight-gradient launches a backward(..., defer_join=True) left running."""
+        main = torch.cuda.current_stream()
+        for ev in ws.__dict__.pop("_deferred_join", []):
+            main.wait_event(ev)

@@ -243,7 +243,9 @@ class _EncoderFrontMixin:
             _lib.check(k.lib.pm_assemble_tokens_bwd(_ptr(dx0), _ptr(ids_keep), _ptr(demb), k.act, _ptr(dcls), _ptr(dpos), B,
                                                     keep, D, _stream()), "pm_assemble_tokens_bwd")
         if need("patch_embed.proj.weight"):
-            k.linear_wgrad(demb, cols, f.grad_view("patch_embed.proj.weight").view(D, PE), B * keep, D, PE, accumulate)
+            # (its own split-K scratch: the last blocks' weight gradients may still be running on the side stream)
+            k.linear_wgrad(demb, cols, f.grad_view("patch_embed.proj.weight").view(D, PE), B * keep, D, PE, accumulate,
+                           ws_name="_ws_front")
         if need("patch_embed.proj.bias"):
             k.colsum(demb, f.grad_view("patch_embed.proj.bias"), B * keep, D)
 
@@ -333,10 +335,13 @@ class _VitClsFn(torch.autograd.Function):
             W, G = rt.stack_weights("blocks.", g.depth)
             cb = (lambda i: sync.block_done("blocks.", i)) if sync is not None else None
             # the incoming dx lives in ws.dx[0]; an odd-depth stack would start writing ws.dx[1] first: fine either way
+            # the embedding's backward does not read the blocks' weight gradients: it runs BEFORE the main stream joins the
+            # side stream, beside the tail block's last weight-gradient launches instead of behind them
             dx0, _ = BlockStack(k, g).backward(ws, x0, W, G, dx, dx_act, False, trainable, front,
-                                               lambda n, i: accumulate, cb)
+                                               lambda n, i: accumulate, cb, defer_join=k.DEFER_JOIN)
             if front and dx0 is not None:
                 _EncoderFrontMixin.front_bwd(rt, dx0, cols, None, B, L, accumulate, need, learn_pos)
+            BlockStack.join_deferred(ws)
         if sync is not None:
             sync.backward_done()
         if ws is not None:
@@ -537,9 +542,10 @@ class _MaeFn(torch.autograd.Function):
         front = need("cls_token") or need("patch_embed.proj.weight") or need("patch_embed.proj.bias")
         cb_e = (lambda i: sync.block_done("blocks.", i)) if sync is not None else None
         dx0, _ = BlockStack(k, ge).backward(ws_e, x0, We, Ge, ws_e.dx[last & 1 ^ 1], ws_e.dx_act[last & 1 ^ 1], True, tr_e,
-                                            front, acc_fn, cb_e)
+                                            front, acc_fn, cb_e, defer_join=k.DEFER_JOIN)
         if front and dx0 is not None:
             _EncoderFrontMixin.front_bwd(rt, dx0, cols, ids_keep, B, keep, accumulate, need, False)
+        BlockStack.join_deferred(ws_e)
         if sync is not None:
             sync.backward_done()
         rt.put_ws(ge, ws_e)
