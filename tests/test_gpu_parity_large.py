@@ -494,3 +494,32 @@ def test_finetune_mode_full_trains_the_positional_table_like_the_reference():
     vm.load_state_dict({n: b for n, b in before.items()}, strict=False)
     A.supervised_loss(vm(imgs.to(DEV)), labels.to(DEV), pos_weight=1.7).backward()
     assert torch.equal(params["pos_embed"].grad, g1)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_mae_vit_large_factory_vs_oracle(prec):
+    """`mae_vit_large_patch16` (models_mae.py:231-236: D = 1024, 24 blocks, 16 heads -- the widest row the LayerNorm kernels hold in
+    registers, a 1024 x 4096 MLP) forward + backward at B = 3 against the oracle with ViT-L geometry.  (ViT-H is not on the HIP
+    path: dh = 80 heads, D = 1280, 14 x 14 patches -- the factory raises at construction; INTEGRATION.md.)"""
+    import ssl4polyp_amd as A
+    from oracle import vit_mae_ref as O
+    cfg = O.ViTConfig(embed_dim=1024, depth=24, num_heads=16)
+    B = 3
+    sd = O.generated_state_dict(cfg, 51, decoder=True, n_class=None)
+    imgs, _, noise = O.generated_batch(cfg, B, 52)
+    _threads()
+    leaves = {n: v.clone().requires_grad_("pos_embed" not in n) for n, v in sd.items()}
+    loss_ref, pred_ref, mask_ref = O.mae_forward(leaves, imgs, noise, cfg)
+    loss_ref.backward()
+    m = A.mae_vit_large_patch16(norm_pix_loss=False, precision=prec)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    loss.backward()
+    assert torch.equal(mask.cpu(), mask_ref)
+    e_loss, e_pred = rel(loss, loss_ref.detach()), rel_l2(pred, pred_ref.detach())
+    worst = max((rel_l2(p.grad, leaves[n].grad), n) for n, p in m.named_parameters()
+                if p.grad is not None and not n.endswith("attn.qkv.bias"))
+    print(f"[parity] mae ViT-L B={B} {prec}: loss rel {e_loss:.3e}, pred rel-L2 {e_pred:.3e}, worst gradient rel-L2 {worst[0]:.3e} ({worst[1]})")
+    t = TOL[prec]
+    assert e_loss < t["loss"] and e_pred < t["pred"] and worst[0] < (1e-3 if prec == "fp32" else 1.5e-2)
