@@ -163,6 +163,8 @@ class Kernels:
     BLOCK_CALLS = os.environ.get("PM_BLOCK_CALLS", "1") != "0"  # block forward as ONE C call (pm_vit_block_fwd) instead of seven
     GROUP_WGRAD = os.environ.get("PM_GROUP_WGRAD", "1") != "0"  # A/B switch: one grouped weight-gradient launch per block
     GROUP_BLOCKS = int(os.environ.get("PM_GROUP_BLOCKS", "0"))  # CUs the grouped launch may take (0 = one workgroup per tile)
+    # the same for a k-sliced group (MAE decoder block: 48 tiles x 4 slices = 192 work items; 0 = one workgroup per item)
+    GROUP_BLOCKS_SLICED = int(os.environ.get("PM_GROUP_BLOCKS_SLICED", "0"))
     GROUP_MIN_TILES = int(os.environ.get("PM_GROUP_MIN_TILES", "64"))
     GROUP_BIAS = os.environ.get("PM_GROUP_BIAS", "1") != "0"    # qkv / fc1 bias gradients inside that launch (no pm_colsum pass)
     GROUP_SPLIT = os.environ.get("PM_GROUP_SPLIT", "1") != "0"  # A/B switch: groups of < 64 tiles as k-sliced grouped launches
@@ -186,7 +188,8 @@ class Kernels:
         key = ("group", K, dt, tuple((tuple(it[2].shape), len(it) > 4 and it[4] is not None) for it in items))
         need = self._need(key, lambda: self.lib.pm_wgrad_group_workspace_bytes(arr, n, K, dt))
         ws = self._scratch("_ws_group", need, items[0][0].device) if need else None
-        st = self.lib.pm_wgrad_group(arr, n, K, dt, self.GROUP_BLOCKS, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+        st = self.lib.pm_wgrad_group(arr, n, K, dt, self.GROUP_BLOCKS_SLICED if need else self.GROUP_BLOCKS, _ptr(ws),
+                                     ws.numel() if ws is not None else 0, _stream())
         if st == _lib.PM_ESHAPE:
             return False
         _lib.check(st, "pm_wgrad_group")
@@ -428,7 +431,7 @@ class BlockStack:
             v(gr["attn.proj.bias"]), v(gr["mlp.fc1.bias"]), v(below_bias),
             v(ws_ln), ws_ln.numel(), v(ws_group), ws_group.numel() if ws_group is not None else 0,
             side.cuda_stream, None, ev_fork.cuda_event, ev_done.cuda_event,
-            ws.B, ws.N, D, Hd, g.heads, k.act, k.gemm_variant, k.GROUP_BLOCKS, acc)
+            ws.B, ws.N, D, Hd, g.heads, k.act, k.gemm_variant, k.GROUP_BLOCKS_SLICED if need else k.GROUP_BLOCKS, acc)
         return desc, ev_done, (ev_fork, ws_ln, ws_group)
 
     def backward(self, ws: StackWorkspace, x_in: torch.Tensor, W, G, dx: torch.Tensor, dx_act: torch.Tensor,
@@ -501,7 +504,7 @@ class BlockStack:
                        int(accumulate("mlp.fc1.weight", i)) << 2 | int(accumulate("mlp.fc2.weight", i)) << 3)
                 key = (dx.data_ptr(), dx_act.data_ptr(), xin.data_ptr(), gr["attn.qkv.weight"].data_ptr(),
                        p["attn.qkv.weight"].data_ptr(), gr["norm1.weight"].data_ptr(),
-                       below_bias.data_ptr() if below_bias is not None else 0, acc, k.gemm_variant, k.GROUP_BLOCKS,
+                       below_bias.data_ptr() if below_bias is not None else 0, acc, k.gemm_variant, k.GROUP_BLOCKS, k.GROUP_BLOCKS_SLICED,
                        ptr_of(k.__dict__.get("_ws_ln")), ptr_of(k.__dict__.get("_ws_group")))  # (scratch is replaced when it grows)
                 ent = bcache.get(i)
                 if ent is None or ent[0] != key:
