@@ -511,16 +511,26 @@ constexpr int V3_KE = 32;                    // bf16 elements of k per stage
 constexpr int V3_STAGE_WAVE = 64 * STAGE_ROW;  // epilogue staging per wave (64 rows x 64 f32, padded)
 
 // One 1-KiB LDS-DMA piece j of a k-normal tile (16 rows x 64 B; the lane's SOURCE chunk is the inverse swizzle of its slot).
+// XOR applied to the 16-B chunk index of row `row` of a k-normal stage image (64-B rows).  S16 = false: the 32x32x16 operand
+// read (lane = row l & 31, k-half l >> 5); S16 = true: the 16x16x32 operand read (lane = row l & 15, chunk l >> 4), for which
+// rows 4q .. 4q+3 take XOR {0, 0, 3, 3}[q]: every 16-lane group of the ds_read_b128 then covers all 16 bank slots once.
+template <bool S16> __device__ __forceinline__ int v3_swz_kn(int row) {
+  const int q = (row >> 2) & 3;
+  if constexpr (S16) return (q >> 1) * 3;
+  else return q;
+}
+
+template <bool S16 = false>
 __device__ __forceinline__ void v3_piece_kn(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
                                             int j, int lane) {
   const int row = 16 * j + (lane >> 2), cs = lane & 3;
-  const int c = cs ^ ((row >> 2) & 3);
+  const int c = cs ^ v3_swz_kn<S16>(row);
   int gr = r0 + row;
   gr = gr < R ? gr : R - 1;
   glds16(base + (long)gr * ld + k0 + c * 8, tile + 1024 * j);
 }
 
-template <int ROWS, int NW = 8>
+template <int ROWS, int NW = 8, bool S16 = false>
 __device__ __forceinline__ void v3_stage_kn(char* tile, const __bf16* __restrict__ base, long ld, int r0, int R, int k0,
                                             int wave, int lane) {
   constexpr int TI = ROWS * 64 / 1024;  // wave-instructions for the tile, dealt round-robin to the NW waves
@@ -528,7 +538,7 @@ __device__ __forceinline__ void v3_stage_kn(char* tile, const __bf16* __restrict
   for (int i = 0; i < (TI + NW - 1) / NW; ++i) {
     const int j = wave + NW * i;
     if (j >= TI) break;  // (192-row tiles: waves 4-7 issue one instruction less)
-    v3_piece_kn(tile, base, ld, r0, R, k0, j, lane);
+    v3_piece_kn<S16>(tile, base, ld, r0, R, k0, j, lane);
   }
 }
 
@@ -559,6 +569,15 @@ __device__ __forceinline__ Frag16 v3_frag_kn(const char* tile, int rb, int kk, i
   const int c = 2 * kk + (lane >> 5);
   Frag16 f;
   f.u = *reinterpret_cast<const u32x4*>(tile + row * 64 + 16 * (c ^ ((row >> 2) & 3)));
+  return f;
+}
+
+// 16 rows x 32 k (one whole 64-B row segment per 4 lanes): the operand of v_mfma_f32_16x16x32_bf16 in ONE ds_read_b128
+__device__ __forceinline__ Frag16 v3_frag16_kn(const char* tile, int rb, int lane) {
+  const int row = rb + (lane & 15);
+  const int c = lane >> 4;
+  Frag16 f;
+  f.u = *reinterpret_cast<const u32x4*>(tile + row * 64 + 16 * (c ^ v3_swz_kn<true>(row)));
   return f;
 }
 
@@ -593,9 +612,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // One block = one BM_ x BN_ output tile (`tile` = row-major tile index, `split_idx` = k-slice for split-K).  The body of
 // gemm_v3_kernel (one GEMM per launch) and of wgrad_group_kernel (the weight gradients of a whole transformer block in
 // one launch, full-K tiles).
+// M16: the k-loop issues v_mfma_f32_16x16x32_bf16 (16 x 16 output tiles, the whole 32-element k-step per instruction) instead of
+// 32x32x16: the same FLOPs per pipe cycle and the same LDS bytes per k-step, but the chip holds a higher clock on it
+// (MI355X_MICROARCH.md, DVFS give-back item 7; measured here with the operand registers of the 32x32x16 loop fed to the other
+// shape: qkv 55.5 -> 48.8 us, fc1+GELU 102 -> 96).  Built for the forward kernels whose both operands are k-normal, on the
+// ping-pong loop with the LDS-staged epilogue (the accumulator layout changes: lane = m % 16, registers = 4 consecutive n).
 template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, bool DIRECT, bool PP, bool XK, int NW, bool SWP,
-          bool XSUM = false>
+          bool XSUM = false, bool M16 = false>
 __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const int split_idx) {
+  static_assert(!M16 || (PP && !DIRECT && !XK && !WK && !XSUM && !SWP && NW == 8), "16x16x32 variant: k-normal ping-pong, staged epilogue");
   constexpr int TM = BM_ / WM, TN = BN_ / WN;      // per-wave tile
   constexpr int MT = TM / 32, NTL = TN / 32;       // 32x32 accumulators per wave
   constexpr int XB = BM_ * 64, WB = BN_ * 64;      // bytes per stage per side
@@ -644,6 +669,12 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
     for (int j = 0; j < MT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  constexpr int NT16 = M16 ? TN / 16 : 1, MT16 = M16 ? TM / 16 : 1;   // 16 x 16 accumulators per wave (M16 only)
+  f32x4 acc16[NT16][MT16];
+#pragma unroll
+  for (int i = 0; i < NT16; ++i)
+#pragma unroll
+    for (int j = 0; j < MT16; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Row sums of the X operand beside the GEMM (grouped weight gradients: X = dY^T, so xsum = the Linear's bias gradient).
   // The 32x32x16 X fragment (lane l: row l&31, k-half l>>5) is fed as the B operand of a 16x16x32 MFMA, which reads it as
@@ -667,9 +698,9 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
   auto issue = [&](int t) {
     char* buf = smem + (t % STAGES) * SB;
     if constexpr (XK) v3_stage_km<BM_, NW>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
-    else v3_stage_kn<BM_, NW>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
+    else v3_stage_kn<BM_, NW, M16>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
     if constexpr (WK) v3_stage_km<BN_, NW>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
-    else v3_stage_kn<BN_, NW>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
+    else v3_stage_kn<BN_, NW, M16>(buf + XB, W, a.ldw, n0, a.N, t * V3_KE, wave, lane);
   };
   auto read_frags = [&](int t, Frag16 (&fw)[2][NTL], Frag16 (&fx)[2][MT]) {
     const char* bx = smem + (t % STAGES) * SB;
@@ -889,7 +920,17 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
       __builtin_amdgcn_s_barrier();  // opens R_t
       PM_STAMP(1);
       Frag16 fw[2][NTL], fx[2][MT];
-      read_frags(t, fw, fx);
+      Frag16 gw[NT16], gx[MT16];
+      if constexpr (M16) {
+        const char* bx = smem + (t % STAGES) * SB;
+        const char* bw = bx + XB;
+#pragma unroll
+        for (int i = 0; i < NT16; ++i) gw[i] = v3_frag16_kn(bw, wn * TN + 16 * i, lane);
+#pragma unroll
+        for (int j = 0; j < MT16; ++j) gx[j] = v3_frag16_kn(bx, wm * TM + 16 * j, lane);
+      } else {
+        read_frags(t, fw, fx);
+      }
       __builtin_amdgcn_sched_barrier(0);
       PM_STAMP(2);
       if (t + DP < nk) issue(t + DP);
@@ -902,7 +943,17 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
       PM_STAMP(5);
       __builtin_amdgcn_s_barrier();  // opens M_t
       PM_STAMP(6);
-      mma_all(fw, fx);
+      if constexpr (M16) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NT16; ++i)
+#pragma unroll
+          for (int j = 0; j < MT16; ++j)
+            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gw[i].h, gx[j].h, acc16[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        mma_all(fw, fx);
+      }
 #ifdef PM_GEMM_STAMP
       PM_STAMP(7);
 #pragma unroll
@@ -1040,17 +1091,27 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
   for (int mh = 0; mh < MT / 2; ++mh) {    // 64 rows of the wave tile per pass
 #pragma unroll
     for (int nh = 0; nh < NTL / 2; ++nh) {  // 64 columns per pass
+      if constexpr (M16) {
+        // 16 x 16 accumulators: lane l holds row m = l & 15, columns n = 4 (l >> 4) .. + 3 of its tile
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ml = j * 32 + (lane & 31);
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int ii = 0; ii < 4; ++ii)
+            *reinterpret_cast<f32x4*>(st + (16 * jj + (lane & 15)) * STAGE_ROW + (16 * ii + 4 * (lane >> 4)) * 4) =
+                acc16[M16 ? nh * 4 + ii : 0][M16 ? mh * 4 + jj : 0];
+      } else {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x16& t16 = acc[nh * 2 + i][mh * 2 + j];
-            const f32x4 v = {t16[4 * g], t16[4 * g + 1], t16[4 * g + 2], t16[4 * g + 3]};
-            *reinterpret_cast<f32x4*>(st + ml * STAGE_ROW + (i * 32 + 8 * g + 4 * h) * 4) = v;
-          }
+        for (int j = 0; j < 2; ++j) {
+          const int ml = j * 32 + (lane & 31);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x16& t16 = acc[nh * 2 + i][mh * 2 + j];
+              const f32x4 v = {t16[4 * g], t16[4 * g + 1], t16[4 * g + 2], t16[4 * g + 3]};
+              *reinterpret_cast<f32x4*>(st + ml * STAGE_ROW + (i * 32 + 8 * g + 4 * h) * 4) = v;
+            }
+        }
       }
       __builtin_amdgcn_wave_barrier();
       const int mw = m0 + wm * TM + mh * 64, nw = n0 + wn * TN + nh * 64;
@@ -1112,9 +1173,9 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
 }
 
 template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false, int NW = 8,
-          bool SWP = false>
+          bool SWP = false, bool M16 = false>
 __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
-  gemm_v3_tile<BM_, BN_, WM, WN, WK, STAGES, DIRECT, PP, XK, NW, SWP>(a, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y);
+  gemm_v3_tile<BM_, BN_, WM, WN, WK, STAGES, DIRECT, PP, XK, NW, SWP, false, M16>(a, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1222,6 +1283,18 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgradGroupArgs 
       }
     }
   }
+}
+
+// forward GEMM on the 16x16x32 loop (both operands k-normal): 256 x 256 ping-pong, LDS-staged epilogue
+int launch_v3_m16(GemmArgs a, hipStream_t s) {
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.N + 255) / 256;
+  constexpr int ring = 4 * 512 * 64, stage = 8 * V3_STAGE_WAVE;
+  const size_t lds = ring > stage ? ring : stage;
+  auto kern = gemm_v3_kernel<256, 256, 2, 4, false, 4, 2, false, true, false, 8, false, true>;
+  PM_ALLOW_LDS(kern, lds);
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
+  return pm_check_launch();
 }
 
 template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, int NW = 8, bool SWP = false>
@@ -1478,6 +1551,8 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
     switch (cfg) {
       case 6: return launch_v3<256, 256, 2, 4, 4, 2, true>(a, b_kmajor, s);          // plain ring loop, register epilogue
       case 8: return launch_v3<256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);   // ping-pong, LDS-staged epilogue
+      case 40: if (!b_kmajor) return launch_v3_m16(a, s);                            // the same on v_mfma_f32_16x16x32_bf16
+               return launch_v3<256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);
       case 9: return launch_v3<256, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);    // ping-pong, register epilogue
       case 10: return launch_v3<192, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);   // 192-row tiles: finer M granularity
       // software-pipelined loop (fragment reads and DMA issue between the wave's own MFMAs)
