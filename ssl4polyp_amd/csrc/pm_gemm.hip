@@ -1659,6 +1659,13 @@ int group_split_target() {
   return v;
 }
 
+// experiment hook, read once: PM_GROUP_FORCE_SPLIT=2|3 cuts the tiles of a LARGE group (ViT-B block: 108 tiles) into k-slices too,
+// so that a launch limited to fewer workgroups than tiles (max_blocks) walks equal shares (scratch/r3_exp17.sh)
+int group_force_split() {
+  static const int v = [] { const char* e = getenv("PM_GROUP_FORCE_SPLIT"); return e && e[0] ? atoi(e) : 0; }();
+  return v;
+}
+
 struct GroupPlan {
   int status;        // PM_OK or the refusal
   int bn;            // tile width
@@ -1686,8 +1693,8 @@ GroupPlan plan_group(const pm_wgrad_item* items, int n, int K, int in_dtype) {
   // block: 48 tiles, K = 50 432 tokens): each tile is cut into k-slices so that tiles x slices ~ the chip (48 x 4 = 192 work
   // items of 394 k-steps), f32 partials in the caller's workspace, ONE reduce launch for the whole group.
   const int nk = K / V3_KE;
-  if (t256 < 64) {
-    int split = (int)(group_split_target() / t256);
+  if (t256 < 64 || group_force_split() > 1) {
+    int split = t256 < 64 ? (int)(group_split_target() / t256) : group_force_split();
     if (split > 8) split = 8;
     if (split > nk / 128) split = nk / 128;  // >= 128 k-steps per slice: prologue / epilogue stay small
     if (split > 1) {
