@@ -116,7 +116,10 @@ typedef struct pm_wgrad_item {
  * A group with fewer than 64 tiles of 256x256 and a long K (the 512-wide MAE decoder block: 48 tiles, K = 50 432 tokens)
  * is cut into k-slices so that tiles x slices fills the chip (48 x 4): f32 partials go to `workspace`
  * (pm_wgrad_group_workspace_bytes; 16-byte aligned) and ONE reduce launch on the same stream finishes every dW / dbias of
- * the group in a fixed order.  With workspace == NULL (or too small) such a group runs whole-K tiles of 256x128 instead. */
+ * the group in a fixed order.  With workspace == NULL (or too small) such a group runs whole-K tiles of 256x128 instead.
+ * max_blocks == PM_GROUP_WHOLE_K: never slice, whole-K tiles of 256x256 whatever the tile count -- for a caller that runs
+ * this group beside another launch of the same kind (pm_vit_block_bwd's second group) and fills the chip that way. */
+#define PM_GROUP_WHOLE_K (-1)
 int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_dtype, int max_blocks, void* workspace, size_t ws_bytes,
                    void* stream);
 size_t pm_wgrad_group_workspace_bytes(const pm_wgrad_item* items, int n, int K, int in_dtype);
@@ -302,6 +305,13 @@ int pm_vit_block_fwd(const pm_block_fwd_desc* d, void* stream);
  * fully trainable block whose four weight gradients fit pm_wgrad_group:
  *   on `stream`:       [wait ev_join]  dfc2 (dGELU) -> dfc1 -> LN2' -> dproj -> attention' -> dqkv -> LN1'
  *   on `side_stream`:  after ev_fork (recorded behind attention'): pm_wgrad_group(fc2, fc1 + bias, proj, qkv + bias) -> ev_done
+ * With two_groups != 0 (and an MLP pair that alone has >= 64 whole-K tiles; otherwise the flag is ignored) the weight
+ * gradients go out as two launches on two side streams, each as soon as its operands exist:
+ *   on `side_stream`:   after ev_fork  (recorded behind dfc2):       pm_wgrad_group(fc2, fc1 + bias)  -> ev_done
+ *   on `side_stream2`:  after ev_fork2 (recorded behind attention'): pm_wgrad_group(proj, qkv + bias) -> ev_done2
+ * so that the 72 + 36 workgroups of a ViT-B block are spread over the whole dgrad chain (the second launch runs on into the
+ * next block's dfc2, which then shares the chip with 36 workgroups instead of 108); the block's matrix gradients are final
+ * once BOTH events have fired.
  * dx / dx_act: gradient of the block output (f32 + act copy); dmid / dmid_act: residual gradient between the branches;
  * din / din_act: gradient of the block input (outputs).  Vector gradients are += targets; g_below_bias receives the column
  * sums of din (bias gradient of the Linear that produced the block input), NULL when there is none; accumulate bit j
@@ -334,6 +344,8 @@ typedef struct pm_block_bwd_desc {
   size_t ws_group_bytes;
   void *side_stream, *ev_join, *ev_fork, *ev_done;
   int samples, N, D, Hd, heads, dtype, gemm_variant, group_blocks, accumulate;
+  int two_groups;                                /* see above; needs the three handles below */
+  void *side_stream2, *ev_fork2, *ev_done2;
 } pm_block_bwd_desc;
 int pm_vit_block_bwd(const pm_block_bwd_desc* d, void* stream);
 

@@ -67,7 +67,7 @@ SIGNATURES = {
     "pm_grad_stats": [P, L, P, P],
 }
 
-ABI_VERSION = 8  # pm_abi_version() of the library these signatures describe
+ABI_VERSION = 9  # pm_abi_version() of the library these signatures describe
 
 WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4
 
@@ -92,7 +92,9 @@ class BlockBwdDesc(ctypes.Structure):
                                         "g_fc2_w", "g_qkv_b", "g_proj_b", "g_fc1_b", "g_below_bias")] +
                 [("ws_ln", c_void_p), ("ws_ln_bytes", ctypes.c_size_t), ("ws_group", c_void_p), ("ws_group_bytes", ctypes.c_size_t)] +
                 [(n, c_void_p) for n in ("side_stream", "ev_join", "ev_fork", "ev_done")] +
-                [(n, c_int) for n in ("samples", "N", "D", "Hd", "heads", "dtype", "gemm_variant", "group_blocks", "accumulate")])
+                [(n, c_int) for n in ("samples", "N", "D", "Hd", "heads", "dtype", "gemm_variant", "group_blocks", "accumulate",
+                                      "two_groups")] +
+                [(n, c_void_p) for n in ("side_stream2", "ev_fork2", "ev_done2")])
 
 
 class BlockFwdDesc(ctypes.Structure):

@@ -69,11 +69,27 @@ extern "C" int pm_vit_block_bwd(const pm_block_bwd_desc* d, void* stream) {
     }
     if ((st = pm_wgrad_group_plan(it, 4, M, dt, nullptr, nullptr, nullptr))) return st;
   }
+  // two launches (fc2, fc1 | proj, qkv) only when the MLP pair alone is a whole-K group; the small pair then runs whole-K too
+  bool two = false;
+  if (d->two_groups) {
+    if (!d->side_stream2 || !d->ev_fork2 || !d->ev_done2) return PM_EINVAL;
+    int slices = 0;
+    if ((st = pm_wgrad_group_plan(it, 2, M, dt, nullptr, nullptr, &slices))) return st;
+    if ((st = pm_wgrad_group_plan(it + 2, 2, M, dt, nullptr, nullptr, nullptr))) return st;
+    two = slices == 1;
+  }
+  hipStream_t side2 = two ? pm_stream(d->side_stream2) : nullptr;
   if (d->ev_join && hipStreamWaitEvent(main, (hipEvent_t)d->ev_join, 0) != hipSuccess) return PM_ELAUNCH;
   // ---- MLP branch
   if ((st = pm_gemm_ex(d->dx_act, D, 0, d->fc2_w, Hd, 1, dt, nullptr, d->d_hidden, Hd, dt, PM_EPI_DGELU, (void*)d->h_pre, nullptr, M,
                        Hd, D, nullptr, 0, &opts, stream)))
     return st;
+  if (two) {  // fc2 / fc1 weight gradients: their operands exist from here on
+    if (hipEventRecord((hipEvent_t)d->ev_fork, main) != hipSuccess) return PM_ELAUNCH;
+    if (hipStreamWaitEvent(side, (hipEvent_t)d->ev_fork, 0) != hipSuccess) return PM_ELAUNCH;
+    if ((st = pm_wgrad_group(it, 2, M, dt, d->group_blocks, nullptr, 0, d->side_stream))) return st;
+    if (hipEventRecord((hipEvent_t)d->ev_done, side) != hipSuccess) return PM_ELAUNCH;
+  }
   if ((st = pm_gemm_ex(d->d_hidden, Hd, 0, d->fc1_w, D, 1, dt, nullptr, d->d_ln, D, dt, PM_EPI_STORE, nullptr, nullptr, M, D, Hd,
                        nullptr, 0, &opts, stream)))
     return st;
@@ -88,10 +104,17 @@ extern "C" int pm_vit_block_bwd(const pm_block_bwd_desc* d, void* stream) {
                              stream)))
     return st;
   // ---- weight gradients of the block: one grouped launch on the side stream, beside the rest of this chain and the next block's
-  if (hipEventRecord((hipEvent_t)d->ev_fork, main) != hipSuccess) return PM_ELAUNCH;
-  if (hipStreamWaitEvent(side, (hipEvent_t)d->ev_fork, 0) != hipSuccess) return PM_ELAUNCH;
-  if ((st = pm_wgrad_group(it, 4, M, dt, d->group_blocks, d->ws_group, d->ws_group_bytes, d->side_stream))) return st;
-  if (hipEventRecord((hipEvent_t)d->ev_done, side) != hipSuccess) return PM_ELAUNCH;
+  if (two) {
+    if (hipEventRecord((hipEvent_t)d->ev_fork2, main) != hipSuccess) return PM_ELAUNCH;
+    if (hipStreamWaitEvent(side2, (hipEvent_t)d->ev_fork2, 0) != hipSuccess) return PM_ELAUNCH;
+    if ((st = pm_wgrad_group(it + 2, 2, M, dt, PM_GROUP_WHOLE_K, nullptr, 0, d->side_stream2))) return st;
+    if (hipEventRecord((hipEvent_t)d->ev_done2, side2) != hipSuccess) return PM_ELAUNCH;
+  } else {
+    if (hipEventRecord((hipEvent_t)d->ev_fork, main) != hipSuccess) return PM_ELAUNCH;
+    if (hipStreamWaitEvent(side, (hipEvent_t)d->ev_fork, 0) != hipSuccess) return PM_ELAUNCH;
+    if ((st = pm_wgrad_group(it, 4, M, dt, d->group_blocks, d->ws_group, d->ws_group_bytes, d->side_stream))) return st;
+    if (hipEventRecord((hipEvent_t)d->ev_done, side) != hipSuccess) return PM_ELAUNCH;
+  }
   // ---- back on the main chain
   if ((st = pm_gemm_ex(d->d_qkv, 3 * D, 0, d->qkv_w, D, 1, dt, nullptr, d->d_ln, D, dt, PM_EPI_STORE, nullptr, nullptr, M, D, 3 * D,
                        nullptr, 0, &opts, stream)))

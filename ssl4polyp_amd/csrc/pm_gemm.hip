@@ -1742,6 +1742,10 @@ extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_d
     pl.split = 1;  // no room for the slabs: whole-K tiles, narrower so that there are twice as many
     pl.bn = 128;
   }
+  if (max_blocks == PM_GROUP_WHOLE_K) {  // the caller pairs this small group with another launch: whole-K 256x256 tiles, no slabs
+    pl.split = 1;
+    pl.bn = 256;
+  }
   const int bn = pl.bn;
   WgradGroupArgs g;
   g.n = n; g.K = K; g.split = pl.split; g.ksteps_split = pl.ksteps_split;

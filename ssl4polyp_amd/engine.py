@@ -85,6 +85,11 @@ class Kernels:
     # stream.  Off: the HBM-bound column sum overlaps the MFMA-bound GEMMs for free, while the fused reduction
     # lengthens the dgrad chain (measured -2.5 % step rate when fused).
     FUSE_COLSUM = os.environ.get("PM_FUSE_COLSUM", "0") == "1"
+    # pm_vit_block_bwd.two_groups: a whole-K block's weight gradients as (fc2, fc1) behind dfc2 and (proj, qkv) behind the
+    # attention backward, on two side streams: each launch starts as soon as its operands exist, and the 72 + 36 workgroups
+    # of a ViT-B block spread over the whole dgrad chain instead of 108 behind the attention backward (measured, 5 pairs of
+    # runs: MAE +0.5 %, cls +0.1 %; gradients bit-identical to the single launch)
+    TWO_GROUPS = os.environ.get("PM_TWO_GROUPS", "1") == "1"
     gemm_variant = int(os.environ.get("PM_GEMM_VARIANT", "0"))  # pm_gemm_opts.variant: 0 = the dispatcher's heuristics (tuning scripts set it per Kernels object)
 
     # -- scratch buffers: sized by the library's own queries (pm_gemm_workspace_bytes / pm_workspace_bytes), cached per
@@ -120,6 +125,13 @@ class Kernels:
         if st is None or st.device != device:
             st = torch.cuda.Stream(device=device)
             self._side = st
+        return st
+
+    def side_stream2(self, device):
+        st = getattr(self, "_side2", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            self._side2 = st
         return st
 
     def _opts(self, wgrad: bool):
@@ -421,6 +433,13 @@ class BlockStack:
         ev_fork, ev_done = torch.cuda.Event(), torch.cuda.Event()
         ev_fork.record(main)   # (materialises the hipEvent_t handles; re-recorded by every call)
         ev_done.record(main)
+        two = bool(k.TWO_GROUPS) and not need
+        ev_fork2 = ev_done2 = side2 = None
+        if two:
+            side2 = k.side_stream2(dx.device)
+            ev_fork2, ev_done2 = torch.cuda.Event(), torch.cuda.Event()
+            ev_fork2.record(main)
+            ev_done2.record(main)
         desc = _lib.BlockBwdDesc(
             v(xin), v(bw.x_mid), v(bw.ln1), v(bw.qkv), v(bw.attn), v(bw.ln2), v(bw.h_pre), v(bw.h_act), v(bw.mean1), v(bw.rstd1),
             v(bw.mean2), v(bw.rstd2), v(bw.lse), v(p["norm1.weight"]), v(p["norm2.weight"]), v(p["attn.qkv.weight"]),
@@ -431,8 +450,9 @@ class BlockStack:
             v(gr["attn.proj.bias"]), v(gr["mlp.fc1.bias"]), v(below_bias),
             v(ws_ln), ws_ln.numel(), v(ws_group), ws_group.numel() if ws_group is not None else 0,
             side.cuda_stream, None, ev_fork.cuda_event, ev_done.cuda_event,
-            ws.B, ws.N, D, Hd, g.heads, k.act, k.gemm_variant, k.GROUP_BLOCKS_SLICED if need else k.GROUP_BLOCKS, acc)
-        return desc, ev_done, (ev_fork, ws_ln, ws_group)
+            ws.B, ws.N, D, Hd, g.heads, k.act, k.gemm_variant, k.GROUP_BLOCKS_SLICED if need else k.GROUP_BLOCKS, acc,
+            int(two), side2.cuda_stream if two else None, ev_fork2.cuda_event if two else None, ev_done2.cuda_event if two else None)
+        return desc, (ev_done, ev_done2) if two else (ev_done,), (ev_fork, ev_fork2, ws_ln, ws_group)
 
     def backward(self, ws: StackWorkspace, x_in: torch.Tensor, W, G, dx: torch.Tensor, dx_act: torch.Tensor,
                  last_bias_grad_done: bool, trainable: Sequence[bool], need_input_grad: bool,
@@ -453,11 +473,12 @@ class BlockStack:
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
         lowest = min([i for i, t in enumerate(trainable) if t], default=g.depth)
         main = torch.cuda.current_stream()
-        pending: Dict[int, torch.cuda.Event] = {}  # block -> side-stream event after its last weight-gradient kernel
+        pending: Dict[int, Tuple[torch.cuda.Event, ...]] = {}  # block -> side-stream event(s) after its last weight-gradient kernels
 
         def join(down_to: int):
             for j in sorted((j for j in pending if j >= down_to), reverse=True):
-                main.wait_event(pending.pop(j))
+                for ev in pending.pop(j):
+                    main.wait_event(ev)
 
         # PM_BLOCK_CALLS: fully trainable, grouped blocks go through pm_vit_block_bwd (one C call per block)
         fast = (k.BLOCK_CALLS and k.GROUP_BIAS and not k.FUSE_COLSUM and dx.is_cuda and
@@ -504,17 +525,22 @@ class BlockStack:
                        int(accumulate("mlp.fc1.weight", i)) << 2 | int(accumulate("mlp.fc2.weight", i)) << 3)
                 key = (dx.data_ptr(), dx_act.data_ptr(), xin.data_ptr(), gr["attn.qkv.weight"].data_ptr(),
                        p["attn.qkv.weight"].data_ptr(), gr["norm1.weight"].data_ptr(),
-                       below_bias.data_ptr() if below_bias is not None else 0, acc, k.gemm_variant, k.GROUP_BLOCKS, k.GROUP_BLOCKS_SLICED,
+                       below_bias.data_ptr() if below_bias is not None else 0, acc, k.gemm_variant, k.GROUP_BLOCKS, k.GROUP_BLOCKS_SLICED, k.TWO_GROUPS,
                        ptr_of(k.__dict__.get("_ws_ln")), ptr_of(k.__dict__.get("_ws_group")))  # (scratch is replaced when it grows)
                 ent = bcache.get(i)
                 if ent is None or ent[0] != key:
                     ent = bcache[i] = (key,) + self._bwd_desc(ws, bw, p, gr, xin, dx, dx_act, dmid, dmid_act, din, din_act,
                                                               d_hidden, d_qkv, below_bias, acc, side, main)
-                _, desc, ev_done, keep = ent
+                _, desc, evs_done, keep = ent
                 _lib.check(k.lib.pm_vit_block_bwd(ctypes.byref(desc), _stream()), "pm_vit_block_bwd")
-                pending[i] = ev_done
+                pending[i] = evs_done
                 if on_block_done is not None:
-                    with torch.cuda.stream(side):
+                    if len(evs_done) == 2:  # the block's gradients are final behind BOTH launches: the later one's stream
+                        last = k.side_stream2(main.device)
+                        last.wait_event(evs_done[0])
+                    else:
+                        last = side
+                    with torch.cuda.stream(last):
                         on_block_done(i)
                 dx, dx_act = din, din_act
                 continue
@@ -564,8 +590,8 @@ class BlockStack:
                         k.linear_wgrad(d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, accumulate("attn.qkv.weight", i))
                     # no join here: the main stream runs on into block i-1 and waits for this event only before
                     # block i-2.  The block's matrix gradients are final in side-stream order.
-                    pending[i] = torch.cuda.Event()
-                    pending[i].record(side)
+                    pending[i] = (torch.cuda.Event(),)
+                    pending[i][0].record(side)
                     if on_block_done is not None:
                         on_block_done(i)
             run_ln1 = need_dx_in or tr
@@ -585,7 +611,7 @@ class BlockStack:
             if on_block_done is not None and not tr:
                 on_block_done(i)
         if defer_join:
-            ws._deferred_join = [pending.pop(j) for j in sorted(pending, reverse=True)]
+            ws._deferred_join = [ev for j in sorted(pending, reverse=True) for ev in pending.pop(j)]
         else:
             join(0)
         return dx, dx_act

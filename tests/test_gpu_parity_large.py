@@ -258,6 +258,9 @@ def test_vitb_mae_fwd_bwd_at_grouped_wgrad_dispatch(prec):
         ws_d = [w for key, lst in rt.pool.items() for w in lst if key[:2] == (512, 8) and w.training][0]
         assert len(ws_d.__dict__.get("_bwd_descs", {})) == 8, "every decoder block through pm_vit_block_bwd (grouped, k-sliced)"
         assert len(ws_e.__dict__.get("_bwd_descs", {})) == 12 - k.UNGROUP_TAIL, "encoder blocks 11..1 grouped, the tail block per GEMM"
+        # whole-K encoder blocks: two launches on two side streams; k-sliced decoder blocks: one (they share the slab workspace)
+        assert all(e[1].two_groups == int(k.TWO_GROUPS) for e in ws_e._bwd_descs.values())
+        assert all(e[1].two_groups == 0 for e in ws_d._bwd_descs.values())
     else:
         assert not k.can_group_wgrad(B * 50, enc_dims) and not k.can_group_wgrad(B * 197, dec_dims)
     t = TOL[prec]
