@@ -25,6 +25,15 @@ import subprocess
 import sys
 import time
 
+# Data-parallel runs use more streams than the HIP runtime has hardware queues by default (4): the engine's four, RCCL's own and the
+# process group's.  Two busy streams on one queue run one after the other, and an event wait of one stalls the other
+# (scratch/r3_exp20.sh: the data-parallel stream schedule on one GPU, 13.1 ms with 4 queues, 11.1 ms with 8, 10.5 ms without RCCL).
+# Read by the runtime when it initialises, so it is set before torch is imported; the plain one-GPU line keeps the default.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-sync" in sys.argv or any(
+        a == "--gpus" and sys.argv[i + 1:i + 2] not in ([], ["1"]) or (a.startswith("--gpus=") and a != "--gpus=1")
+        for i, a in enumerate(sys.argv)):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 import torch.distributed as dist
 
@@ -81,13 +90,16 @@ def parse():
     ap.add_argument("--finetune-mode", choices=["none", "head+1", "head+2", "full"], default="full",
                     help="C5 regime of the cls workload (classification/finetune.py:49-91): linear probe / lin_head + the last 1 or "
                          "2 blocks / everything.  The default line (full) also carries the other three as `finetune_modes`")
+    ap.add_argument("--force-sync", action="store_true",
+                    help="N=1 only: run the bucketed RCCL gradient all-reduces at world size 1 (the multi-GPU stream schedule -- "
+                         "comm stream, RCCL's own stream -- on one GPU: what the data-parallel path costs before any link is involved)")
     ap.add_argument("--no-c5", action="store_true", help="skip the `finetune_modes` sub-records (none / head+1 / head+2 + eval)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step as one hipGraph (auto = off: eager launch keeps up and overlaps the two streams better)")
     return ap.parse_args()
 
 
-def build(workload, precision, device, world, batch, finetune_mode="full"):
+def build(workload, precision, device, world, batch, finetune_mode="full", force_sync=False):
     import ssl4polyp_amd as A
     from ssl4polyp_amd.optim import FusedAdamW, add_weight_decay
     from ssl4polyp_amd.parallel import DataParallel
@@ -100,7 +112,7 @@ def build(workload, precision, device, world, batch, finetune_mode="full"):
         configure_finetune_parameters(model, finetune_mode)
     else:
         model = A.mae_vit_base_patch16(norm_pix_loss=False, precision=precision)
-    ddp = DataParallel(model, device)
+    ddp = DataParallel(model, device, force_sync=force_sync)
     if workload == "cls":
         # tc.py:5751-5768: AdamW(lr 1e-3, wd 0.05) over two groups head / backbone (config/base.yaml:1-4), built from ALL
         # parameters: frozen ones stay in the optimizer and are skipped for want of a gradient
@@ -191,9 +203,9 @@ def kernel_stats(model, step):
         lay = ("tn" if akm else "n") + ("n" if bkm else "t")
         rec.append((lay if akm else f"{lay}_{EPI.get(epi, epi)}", M, N, K, e0, e1))
 
-    def wgrad_group(items, K):
+    def wgrad_group(items, K, **kw):
         e0, e1 = ev2()
-        e0.record(); ok = orig["wg"](items, K); e1.record()
+        e0.record(); ok = orig["wg"](items, K, **kw); e1.record()
         if ok:
             rec.append(("wgrad_group", sum(it[2].shape[0] * it[2].shape[1] for it in items), 1, K, e0, e1))
         return ok
@@ -553,7 +565,7 @@ def torch_baseline(device, batch, steps=10, warmup=3):
 def run_workload(args, workload, batch, device, world, rank, headline, finetune_mode="full", light=False):
     """Build, warm up, time exactly args.steps steps (barrier + synchronize on both sides, max over ranks).
     light: a C5 sub-record -- no kernel statistics, parity against the cached oracle run of the headline, + eval forward."""
-    model, ddp, opt = build(workload, args.precision, device, world, batch, finetune_mode)
+    model, ddp, opt = build(workload, args.precision, device, world, batch, finetune_mode, force_sync=args.force_sync and world == 1)
     imgs, labels = make_batch(workload, batch, device, rank)
     eager_step = make_step(workload, ddp, opt, imgs, labels, args.lr_every_step)
     use_graph = args.graph == "on"  # auto: eager (measured faster: graph replay serialises the wgrad side stream)
@@ -728,13 +740,13 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
             names = {"nt_store": "gemm_v3_kernel (forward, act-typed output: qkv, decoder_pred ...)",
                      "nt_gelu": "gemm_v3_kernel (forward fc1 + GELU)", "nt_residual": "gemm_v3_kernel (forward, f32 residual epilogue: proj / fc2)",
                      "nn_store": "gemm_v3_kernel (dgrad: dY [M,K] x W [K,N])", "nn_dgelu": "gemm_v3_kernel (dgrad fc2 + dGELU)",
-                     "tnn": "gemm_v3_kernel (split-K weight gradient)", "wgrad_group": "wgrad_group_kernel (all dW of a block, full-K tiles)"}
+                     "tnn": "gemm_v3_kernel (split-K weight gradient)", "wgrad_group": "wgrad_group_kernel (the dW of a block in two launches, full-K tiles)"}
             roof["kernel"] = {"name": names.get(dom[0], dom[0]), "class": dom[0], **dom[1],
                               "frac": round(dom[1]["tflops"] / peak, 4),
                               "share_of_gemm_time": round(dom[1]["launches"] * dom[1]["avg_us"] * 1e-6 / max(gt, 1e-12), 3),
                               "note": "the class with the largest summed in-step launch time (HIP events on its own stream); "
                                       "launches of the forward chains / of the dgrad and weight-gradient streams overlap, so "
-                                      "each shares the CUs (the grouped weight gradients take ~108 of the 256 CUs by design; "
+                                      "each shares the CUs (the grouped weight gradients take 72 + 36 of the 256 CUs by design; "
                                       "stand-alone rates: DESIGN.md)"}
             try:  # PMC traffic of the dominant kernel, from the committed rocprofv3 --pmc passes (profiles/)
                 with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as fh:
@@ -754,7 +766,8 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
                "host_enqueue_ms_per_step": round(t_enq * 1e3, 3), "step_ms": step_ms, "preheat_steps": preheat_steps,
                "config": {"workload": WORKLOAD_NAME[workload] + f", bs={batch}/GPU, 224^2, AdamW, random init"
                                       + (f", finetune mode {finetune_mode} (finetune.py:49-91)" if workload == "cls" else ""),
-                          "global_batch": batch * world, "parallelism": f"dp{world}", "final_loss": round(loss_val, 5),
+                          "global_batch": batch * world, "parallelism": f"dp{world}" + ("+forced world-1 RCCL all-reduces" if ddp.sync is not None and world == 1 else ""),
+                          "final_loss": round(loss_val, 5),
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "lr_schedule": ("per-iteration warm-up (engine_pretrain.py:47-48; 40 epochs x 390 it)" if workload == "mae"
                                           else "new lr every step" if args.lr_every_step else "constant")},
@@ -914,12 +927,21 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    import ssl4polyp_amd
+    if os.environ.get("BENCH_LATE_STREAMS") != "1":  # (A/B switch of scratch/r3_exp20.sh)
+        ssl4polyp_amd.reserve_streams(device)  # before RCCL creates its streams: one hardware queue per engine stream
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+    elif args.force_sync:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
     batch = args.batch or (64 if args.workload == "cls" else 256)
     head = run_workload(args, args.workload, batch, device, world, rank, True, finetune_mode=args.finetune_mode)
     sub = None
@@ -968,10 +990,10 @@ def main():
                 if rec for k in rec.get("hard_fail", [])]
         if hard:
             print("[bench] PARITY GATE FAILED: " + ", ".join(hard), file=sys.stderr, flush=True)
-            if world > 1:
+            if dist.is_initialized():
                 dist.destroy_process_group()
             sys.exit(4)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -68,6 +68,7 @@ SIGNATURES = {
 }
 
 ABI_VERSION = 9  # pm_abi_version() of the library these signatures describe
+PM_GROUP_WHOLE_K = -1  # pm_wgrad_group(max_blocks=...): never slice, whole-K 256x256 tiles
 
 WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4
 

@@ -51,6 +51,34 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_STREAMS: Dict[Tuple[int, str], "torch.cuda.Stream"] = {}
+
+
+def _shared_stream(device, role: str):
+    """The process-wide side stream of this role ("aux0", "side", "side2", ...) on `device`, created on first use."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), role)
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def reserve_streams(device) -> None:
+    """Create the engine's side streams on `device` and put one tiny launch on each, NOW.  The HIP runtime binds a stream to one
+    of its few hardware queues (GPU_MAX_HW_QUEUES, 4) when the stream is first used, least-loaded queue first: called before
+    anything else creates streams -- in particular before torch.distributed / RCCL initialise, which use half a dozen of their
+    own -- the main stream and the three side streams each get a queue to themselves.  Called late, two of them can land on one
+    queue and run one after the other (measured with RCCL initialised first: the second forward chain behind the main stream,
+    cls step 15.0 instead of 10.6 ms)."""
+    dev = torch.device(device)
+    torch.zeros(1, device=dev)  # (the main stream first)
+    for role in ("aux0", "side", "side2"):
+        with torch.cuda.stream(_shared_stream(dev, role)):
+            torch.zeros(1, device=dev)
+    torch.cuda.synchronize(dev)
+
+
 class Kernels:
     """Thin typed wrappers: torch tensors in, C-ABI calls out (include/polypmae.h)."""
 
@@ -111,27 +139,23 @@ class Kernels:
             setattr(self, name, ws)
         return ws
 
+    # The side streams are shared by every Kernels object of the process (one set per device): the HIP runtime multiplexes
+    # streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams on one queue run their
+    # kernels one after the other.  A stream set per model put the third model's weight-gradient stream onto the main
+    # stream's queue (bench.py builds several models in one process: the MAE step lost 11 %).
     def aux_stream(self, device, j: int = 0):
-        pool = getattr(self, "_aux", None)
-        if pool is None or (pool and pool[0].device != device):
-            pool = []
-            self._aux = pool
-        while len(pool) <= j:
-            pool.append(torch.cuda.Stream(device=device))
-        return pool[j]
+        return _shared_stream(device, f"aux{j}")
 
     def side_stream(self, device):
         st = getattr(self, "_side", None)
         if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
-            self._side = st
+            st = self._side = _shared_stream(device, "side")
         return st
 
     def side_stream2(self, device):
         st = getattr(self, "_side2", None)
         if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
-            self._side2 = st
+            st = self._side2 = _shared_stream(device, "side2")
         return st
 
     def _opts(self, wgrad: bool):
@@ -185,11 +209,11 @@ class Kernels:
     # (whole-chip split-K launches, each as soon as its dY exists).
     UNGROUP_TAIL = int(os.environ.get("PM_UNGROUP_TAIL", "1"))
 
-    def wgrad_group(self, items, K) -> bool:
+    def wgrad_group(self, items, K, whole_k: bool = False) -> bool:
         """items: [(dy [K, n_out], x [K, n_in], dW f32 [n_out, n_in], accumulate[, dbias f32 [n_out] (+=)])].  One launch for all
         (pm_wgrad_group; a group of few tiles and long K is cut into k-slices: slabs in a scratch buffer sized by
         pm_wgrad_group_workspace_bytes, one reduce launch); False when the shapes do not fit the grouped kernel (the caller
-        then uses linear_wgrad)."""
+        then uses linear_wgrad).  whole_k: PM_GROUP_WHOLE_K -- never slice (the second launch of a two-launch block)."""
         n = len(items)
         arr = (_lib.WgradItem * n)()
         for j, (dy, x, dW, acc, *rest) in enumerate(items):
@@ -198,10 +222,10 @@ class Kernels:
                                     _ptr(rest[0]) if rest and rest[0] is not None else None)
         dt = _lib.dtype_code(items[0][0].dtype)
         key = ("group", K, dt, tuple((tuple(it[2].shape), len(it) > 4 and it[4] is not None) for it in items))
-        need = self._need(key, lambda: self.lib.pm_wgrad_group_workspace_bytes(arr, n, K, dt))
+        need = 0 if whole_k else self._need(key, lambda: self.lib.pm_wgrad_group_workspace_bytes(arr, n, K, dt))
         ws = self._scratch("_ws_group", need, items[0][0].device) if need else None
-        st = self.lib.pm_wgrad_group(arr, n, K, dt, self.GROUP_BLOCKS_SLICED if need else self.GROUP_BLOCKS, _ptr(ws),
-                                     ws.numel() if ws is not None else 0, _stream())
+        blocks = _lib.PM_GROUP_WHOLE_K if whole_k else (self.GROUP_BLOCKS_SLICED if need else self.GROUP_BLOCKS)
+        st = self.lib.pm_wgrad_group(arr, n, K, dt, blocks, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
         if st == _lib.PM_ESHAPE:
             return False
         _lib.check(st, "pm_wgrad_group")
@@ -230,6 +254,27 @@ class Kernels:
         ok = st == 0 and (tiles.value >= self.GROUP_MIN_TILES or (self.GROUP_SPLIT and slices.value > 1))
         cache[key] = ok
         return ok
+
+    def two_launch_group(self, K: int, dims) -> bool:
+        """May a grouped block (dims = fc2, fc1, proj, qkv) go out as two launches -- (fc2, fc1) and (proj, qkv) -- on two side
+        streams (pm_block_bwd_desc.two_groups)?  Yes when the first pair alone is a whole-K group by the library's plan (no
+        slabs: the two launches must not share a workspace); the second pair then runs whole-K too (PM_GROUP_WHOLE_K)."""
+        if not self.TWO_GROUPS:
+            return False
+        key = ("two_launch", K, self.act, tuple(dims))
+        cache = self.__dict__.setdefault("_need_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            ok = True
+            for first, part in ((True, dims[:2]), (False, dims[2:])):
+                arr = (_lib.WgradItem * 2)()
+                for j, (o, i) in enumerate(part):
+                    arr[j] = _lib.WgradItem(64, o, 64, i, 64, i, o, i, 0, None)
+                slices = ctypes.c_int(0)
+                st = self.lib.pm_wgrad_group_plan(arr, 2, K, self.act, None, None, ctypes.byref(slices))
+                ok = ok and st == 0 and (slices.value == 1 or not first)
+            hit = cache[key] = ok
+        return hit
 
     def linear_wgrad(self, dy, x, dW, M, N_out, K_in, accumulate, ws_name="_ws"):
         """dW[N_out,K_in] (+)= dy[M,N_out]^T @ x[M,K_in]  (both operands k-major, f32 output).  ws_name: the split-K slab
@@ -433,7 +478,7 @@ class BlockStack:
         ev_fork, ev_done = torch.cuda.Event(), torch.cuda.Event()
         ev_fork.record(main)   # (materialises the hipEvent_t handles; re-recorded by every call)
         ev_done.record(main)
-        two = bool(k.TWO_GROUPS) and not need
+        two = not need and k.two_launch_group(M, ((D, Hd), (Hd, D), (D, D), (3 * D, D)))
         ev_fork2 = ev_done2 = side2 = None
         if two:
             side2 = k.side_stream2(dx.device)
@@ -551,6 +596,14 @@ class BlockStack:
                     k.linear_wgrad(dx_act, bw.h_act, gr["mlp.fc2.weight"], M, D, Hd, accumulate("mlp.fc2.weight", i))
             # fc1.bias gradient = column sums of d_hidden: optionally fused into the dGELU epilogue that produces it
             fuse_cs = tr and k.FUSE_COLSUM
+            # the launcher's two-launch schedule, kernel by kernel: (fc2, fc1) behind dfc2 on the side stream, (proj, qkv) behind
+            # the attention backward on the second one
+            two = (grouped and k.GROUP_BIAS and not fuse_cs and
+                   k.two_launch_group(M, ((D, Hd), (Hd, D), (D, D), (3 * D, D))))
+            group_mlp = [(dx_act, bw.h_act, gr["mlp.fc2.weight"], accumulate("mlp.fc2.weight", i)),
+                         (d_hidden, bw.ln2, gr["mlp.fc1.weight"], accumulate("mlp.fc1.weight", i),
+                          gr["mlp.fc1.bias"] if (grouped and k.GROUP_BIAS and not fuse_cs) else None)] if grouped else None
+            ev_mlp = None
             k.linear_dgrad(dx_act, p["mlp.fc2.weight"], d_hidden, M, D, Hd, EPI_DGELU, aux=bw.h_pre,
                            colsum=gr["mlp.fc1.bias"] if fuse_cs else None)
             if tr:
@@ -560,6 +613,11 @@ class BlockStack:
                         k.linear_wgrad(d_hidden, bw.ln2, gr["mlp.fc1.weight"], M, Hd, D, accumulate("mlp.fc1.weight", i))
                     if not fuse_cs and not (grouped and k.GROUP_BIAS):
                         k.colsum(d_hidden, gr["mlp.fc1.bias"], M, Hd)
+                    if two:
+                        if not k.wgrad_group(group_mlp, M):
+                            raise _lib.PolypMaeError("pm_wgrad_group refused a group that two_launch_group admitted")
+                        ev_mlp = torch.cuda.Event()
+                        ev_mlp.record(side)
             k.linear_dgrad(d_hidden, p["mlp.fc1.weight"], ws.d_ln, M, Hd, D)
             k.layernorm_bwd(ws.d_ln, bw.x_mid, p["norm2.weight"], bw.mean2, bw.rstd2, dx, dmid, dmid_act,
                             gr["norm2.weight"] if tr else None, gr["norm2.bias"] if tr else None,
@@ -572,27 +630,31 @@ class BlockStack:
             k.linear_dgrad(dmid_act, p["attn.proj.weight"], ws.d_attn, M, D, D)
             k.attention_bwd(bw.qkv, bw.attn, ws.d_attn, bw.lse, ws.delta, d_qkv, B, N, g.heads, g.dh)
             if tr:
-                fork()
-                with torch.cuda.stream(side):
+                last = k.side_stream2(main.device) if two else side
+                ev = torch.cuda.Event()
+                ev.record(main)
+                last.wait_event(ev)
+                with torch.cuda.stream(last):
                     gb = grouped and k.GROUP_BIAS  # bias gradients (column sums of dY) inside the grouped launch
                     if not gb:
                         k.colsum(d_qkv, gr["attn.qkv.bias"], M, 3 * D)
                     if grouped:
-                        ok = k.wgrad_group([(dx_act, bw.h_act, gr["mlp.fc2.weight"], accumulate("mlp.fc2.weight", i)),
-                                            (d_hidden, bw.ln2, gr["mlp.fc1.weight"], accumulate("mlp.fc1.weight", i),
-                                             gr["mlp.fc1.bias"] if (gb and not fuse_cs) else None),
-                                            (dmid_act, bw.attn, gr["attn.proj.weight"], accumulate("attn.proj.weight", i)),
-                                            (d_qkv, bw.ln1, gr["attn.qkv.weight"], accumulate("attn.qkv.weight", i),
-                                             gr["attn.qkv.bias"] if gb else None)], M)
+                        group_attn = [(dmid_act, bw.attn, gr["attn.proj.weight"], accumulate("attn.proj.weight", i)),
+                                      (d_qkv, bw.ln1, gr["attn.qkv.weight"], accumulate("attn.qkv.weight", i),
+                                       gr["attn.qkv.bias"] if gb else None)]
+                        ok = k.wgrad_group(group_attn, M, whole_k=True) if two else k.wgrad_group(group_mlp + group_attn, M)
                         if not ok:
                             raise _lib.PolypMaeError("pm_wgrad_group refused a group that can_group_wgrad admitted")
                     else:
                         k.linear_wgrad(d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, accumulate("attn.qkv.weight", i))
-                    # no join here: the main stream runs on into block i-1 and waits for this event only before
-                    # block i-2.  The block's matrix gradients are final in side-stream order.
-                    pending[i] = (torch.cuda.Event(),)
-                    pending[i][0].record(side)
+                    # no join here: the main stream runs on into block i-1 and waits for these events only before
+                    # block i-2.  The block's matrix gradients are final behind the last launch of each stream.
+                    ev_last = torch.cuda.Event()
+                    ev_last.record(last)
+                    pending[i] = (ev_mlp, ev_last) if two else (ev_last,)
                     if on_block_done is not None:
+                        if two:
+                            last.wait_event(ev_mlp)
                         on_block_done(i)
             run_ln1 = need_dx_in or tr
             if run_ln1:

@@ -59,6 +59,8 @@ def run(args, data_loader=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    from .engine import reserve_streams
+    reserve_streams(device)  # before RCCL creates its streams: one hardware queue per engine stream (engine.reserve_streams)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)

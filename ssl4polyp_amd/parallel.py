@@ -25,6 +25,7 @@ Gradients are summed; the mean is folded into the fused AdamW (``grad_scale = 1/
 """
 from __future__ import annotations
 
+import warnings
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -41,7 +42,6 @@ class GradSync:
         self.merge_gap = int(merge_gap)
         self.force = bool(force)  # run the collectives at world size 1 too (tests: exercises the RCCL stream semantics)
         self.enabled = True       # False inside no_sync() (gradient accumulation micro-steps)
-        self.comm_stream: Optional[torch.cuda.Stream] = None
         self._works: List = []
         self._hi = None           # everything in mat[_hi:] has been handed to RCCL
         self._armed = False
@@ -84,8 +84,6 @@ class GradSync:
 
     def _begin(self):
         f = self.rt.flat
-        if self.comm_stream is None and f.device.type == "cuda":
-            self.comm_stream = torch.cuda.Stream(device=f.device)
         self._plan()
         self._hi = f.G["mat"].numel()
         self._works = []
@@ -98,11 +96,11 @@ class GradSync:
         if not tensor.is_cuda:  # gloo rehearsal of the bucket schedule on CPU (tests)
             self._works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.comm_stream.wait_event(ev)
-        with torch.cuda.stream(self.comm_stream):
-            self._works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        # Issued from the weight-gradient stream the engine calls us on (the gradients are final in ITS order): the process
+        # group's own RCCL stream waits for that stream's work so far, the collective runs there, and wait() orders the
+        # optimizer's stream behind it.  No stream of our own in between: every extra stream is one more candidate for
+        # sharing a hardware queue with the main stream (engine.reserve_streams).
+        self._works.append(dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _pending(self, lo: int, hi: int) -> List[Tuple[int, int]]:
         """Trainable pieces of mat[lo:hi), back to front."""
@@ -165,6 +163,13 @@ class DataParallel(nn.Module):
         rt = module._rt
         rt.ensure(device)
         if dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force_sync):
+            from . import engine
+            dev = torch.device(device)
+            if dev.type == "cuda" and not any(k[1] == "side" for k in engine._STREAMS):
+                warnings.warn("ssl4polyp_amd.reserve_streams(device) was not called before torch.distributed initialised: the "
+                              "engine's side streams may share a hardware queue with RCCL's or with the main stream and then "
+                              "run one after the other (up to 1.4x step time measured).  Call it right after "
+                              "torch.cuda.set_device(), and export GPU_MAX_HW_QUEUES=8 before the process starts.", stacklevel=2)
             for r in ("vec", "mat"):
                 dist.broadcast(rt.flat.P[r], src=0, group=process_group)
             rt.flat._shadow_versions = None  # force a shadow refresh from the broadcast weights

@@ -680,6 +680,52 @@ def test_wgrad_group(K, dims):
     assert not k.wgrad_group(items, 1024)
 
 
+def test_wgrad_group_whole_k_flag():
+    """max_blocks = PM_GROUP_WHOLE_K (pm_vit_block_bwd's second launch: proj + qkv of a ViT-B block, 36 tiles): the plan would cut
+    this group into k-slices; with the flag it runs whole-K 256x256 tiles without a workspace -- and every tile then sums in the
+    same order as inside the unsliced four-problem group of the block, so the two agree bit for bit."""
+    import ctypes
+    from ssl4polyp_amd import _lib
+    k = _k("bf16")
+    bf = torch.bfloat16
+    K, D = 12608, 768  # (64 x 197 tokens: long enough for the plan to slice the small group)
+    dims = ((D, 4 * D), (4 * D, D), (D, D), (3 * D, D))
+    ops = []
+    for j, (n_out, n_in) in enumerate(dims):
+        ops.append((rnd(K, n_out, seed=500 + j, scale=0.5).to(bf), rnd(K, n_in, seed=510 + j, scale=0.5).to(bf)))
+
+    def items(sel, fill):
+        out = []
+        for j in sel:
+            n_out, n_in = dims[j]
+            out.append((ops[j][0], ops[j][1], torch.full((n_out, n_in), fill, device=DEV), False,
+                        torch.zeros(n_out, device=DEV) if j in (1, 3) else None))
+        return out
+
+    def launch(its, max_blocks):
+        n = len(its)
+        arr = (_lib.WgradItem * n)()
+        for j, (dy, x, dW, acc, db) in enumerate(its):
+            n_out, n_in = dW.shape
+            arr[j] = _lib.WgradItem(dy.data_ptr(), n_out, x.data_ptr(), n_in, dW.data_ptr(), n_in, n_out, n_in, 0,
+                                    db.data_ptr() if db is not None else None)
+        slices = ctypes.c_int(0)
+        assert k.lib.pm_wgrad_group_plan(arr, n, K, _lib.PM_BF16, None, None, ctypes.byref(slices)) == 0
+        _lib.check(k.lib.pm_wgrad_group(arr, n, K, _lib.PM_BF16, max_blocks, None, 0, torch.cuda.current_stream().cuda_stream),
+                   "pm_wgrad_group")
+        torch.cuda.synchronize()
+        return slices.value
+
+    whole = items(range(4), float("nan"))
+    assert launch(whole, 0) == 1                      # 108 tiles: whole-K by itself
+    small = items((2, 3), float("nan"))
+    assert launch(small, _lib.PM_GROUP_WHOLE_K) > 1   # 36 tiles: the plan alone would slice ...
+    for a, b in zip(small, whole[2:]):                # ... the flag keeps whole-K tiles: same bits as in the big group
+        assert torch.equal(a[2], b[2])
+        assert (a[4] is None) == (b[4] is None) and (a[4] is None or torch.equal(a[4], b[4]))
+    assert rel(small[1][2], ops[3][0].float().t() @ ops[3][1].float()) < 3e-5 * math.sqrt(K / 32)
+
+
 def test_mae_noise_is_the_counter_based_generator_bit_for_bit():
     """pm_mae_noise (Philox4x32-10, the noise of random_masking, models_mae.py:132) against oracle/noise_ref.py -- itself
     pinned by Random123's known-answer vectors -- for odd sizes, 64-bit seeds and several streams; and the model-level contract:

@@ -52,3 +52,20 @@ def test_async_schedule_equals_serialised_runtime(tmp_path, workload, steps):
     assert a["sd"].keys() == b["sd"].keys()
     for k in a["sd"]:
         assert torch.equal(a["sd"][k], b["sd"][k]), k
+
+
+@pytest.mark.gpu
+def test_side_streams_are_shared_by_every_model_of_the_process():
+    """One set of side streams per device (engine._shared_stream): the HIP runtime multiplexes streams onto a few hardware queues, and
+    a set per model put a later model's weight-gradient stream onto the main stream's queue (the MAE step of the multi-model bench
+    line lost 11 %).  reserve_streams() creates them up front and is idempotent."""
+    import ssl4polyp_amd as A
+    from ssl4polyp_amd import engine
+    DEV = torch.device("cuda", 0)
+    A.reserve_streams(DEV)
+    first = {role: engine._shared_stream(DEV, role) for role in ("aux0", "side", "side2")}
+    A.reserve_streams(DEV)
+    k1, k2 = engine.Kernels("bf16"), engine.Kernels("fp32")
+    for k in (k1, k2):
+        assert k.aux_stream(DEV, 0) is first["aux0"] and k.side_stream(DEV) is first["side"] and k.side_stream2(DEV) is first["side2"]
+    assert len({s.cuda_stream for s in first.values()} | {torch.cuda.current_stream().cuda_stream}) == 4
