@@ -25,15 +25,6 @@ import subprocess
 import sys
 import time
 
-# Data-parallel runs use more streams than the HIP runtime has hardware queues by default (4): the engine's four, RCCL's own and the
-# process group's.  Two busy streams on one queue run one after the other, and an event wait of one stalls the other
-# (scratch/r3_exp20.sh: the data-parallel stream schedule on one GPU, 13.1 ms with 4 queues, 11.1 ms with 8, 10.5 ms without RCCL).
-# Read by the runtime when it initialises, so it is set before torch is imported; the plain one-GPU line keeps the default.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-sync" in sys.argv or any(
-        a == "--gpus" and sys.argv[i + 1:i + 2] not in ([], ["1"]) or (a.startswith("--gpus=") and a != "--gpus=1")
-        for i, a in enumerate(sys.argv)):
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import torch
 import torch.distributed as dist
 

@@ -3,13 +3,6 @@
 Public surface mirrors the reference's model factories (src/ssl4polyp/utils/__init__.py:29-67,
 src/ssl4polyp/models/mae/models_mae.py:223-250).
 """
-import os as _os
-
-# A data-parallel rank uses more busy streams than the HIP runtime has hardware queues by default (4): ask for 8 before the runtime
-# initialises (it reads the variable once).  See engine.reserve_streams and DESIGN.md section 5.
-if int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1:
-    _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 from .models import (MaskedAutoencoderViT, ViT_from_MAE, VisionTransformer_from_Any, get_ImageNet_or_random_ViT,
                      get_MAE_backbone, mae_vit_base_patch16, mae_vit_huge_patch14, mae_vit_large_patch16, supervised_loss)
 from .engine import reserve_streams

@@ -12,6 +12,7 @@ arithmetic (`pm_aug_*`, csrc/pm_augment.hip), so the workers are left with JPEG 
 from __future__ import annotations
 
 import concurrent.futures
+import os
 from typing import Iterable, Iterator, Optional, Sequence, Tuple
 
 import torch
@@ -310,10 +311,19 @@ class DevicePrefetcher:
     RandomVerticalFlip of the reference's train transform) from `generator`."""
 
     def __init__(self, loader: Iterable, device, mean: Sequence[float] = IMAGENET_MEAN, std: Sequence[float] = IMAGENET_STD,
-                 flip_p: float = 0.0, generator: Optional[torch.Generator] = None, augment: Optional["DeviceAugmenter"] = None):
+                 flip_p: float = 0.0, generator: Optional[torch.Generator] = None, augment: Optional["DeviceAugmenter"] = None,
+                 stream: str = "auto"):
         """augment: a DeviceAugmenter -> the loader may yield decoded frames of any (batch-uniform) size and the WHOLE train
         transform of the reference (Resize, ColorJitter, GaussianBlur(25), flips, RandomRotation(180), ToTensor, Normalize) runs
-        on the copy stream; `flip_p` is then ignored (the augmenter draws its own flips from `generator`)."""
+        on the copy stream; `flip_p` is then ignored (the augmenter draws its own flips from `generator`).
+        stream: where the copies and the transform run -- "own": a stream of the prefetcher (a fourth busy stream beside the
+        engine's three: one hardware queue each, fastest on a single GPU); "side": the engine's weight-gradient stream (idle
+        during the forward pass, when the next batch is staged) -- for data-parallel ranks, where RCCL's stream is the fourth busy
+        one and a fifth would share a queue with the main stream (13.9 instead of 11.6 ms per step measured, DESIGN.md section 5);
+        "auto": "side" when a torch.distributed process group is initialised, "own" otherwise."""
+        if stream not in ("auto", "own", "side"):
+            raise ValueError("stream must be 'auto', 'own' or 'side'")
+        self.stream_mode = stream
         self.loader, self.device = loader, torch.device(device)
         self.mean, self.std, self.flip_p, self.generator = mean, std, float(flip_p), generator
         self.augment = augment
@@ -377,7 +387,15 @@ class DevicePrefetcher:
         if self.device.type != "cuda":
             raise _lib.PolypMaeError("DevicePrefetcher needs a GPU (the transform tail is a HIP kernel)")
         if self._stream is None:
-            self._stream = torch.cuda.Stream(device=self.device)
+            mode = {"0": "own", "1": "side"}.get(os.environ.get("PM_PREFETCH_ON_SIDE", ""), self.stream_mode)  # (A/B switch)
+            if mode == "auto":
+                import torch.distributed as dist
+                mode = "side" if dist.is_available() and dist.is_initialized() else "own"
+            if mode == "side":
+                from .engine import _shared_stream
+                self._stream = _shared_stream(self.device, "side")
+            else:
+                self._stream = torch.cuda.Stream(device=self.device)
         it = iter(self.loader)
         # Staging runs on a worker thread: the pinned-memory copy and the host-to-device enqueue block their caller for
         # about as long as a CPU memcpy of the batch (1 ms per 64 frames measured), and the main thread must spend that

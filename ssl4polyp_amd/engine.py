@@ -52,6 +52,10 @@ def _stream() -> int:
 
 
 _STREAMS: Dict[Tuple[int, str], "torch.cuda.Stream"] = {}
+# The second weight-gradient stream (busy in the backward only) IS the second forward chain's stream (busy in the forward only):
+# three engine streams + the main stream = four busy streams at most, one per hardware queue of the runtime's default, and one queue
+# left for RCCL in a data-parallel rank (scratch/r3_exp23.sh; PM_MERGE_AUX_SIDE2=0 gives the weight gradients a stream of their own)
+MERGE_AUX_SIDE2 = os.environ.get("PM_MERGE_AUX_SIDE2", "1") == "1"
 
 
 def _shared_stream(device, role: str):
@@ -66,14 +70,14 @@ def _shared_stream(device, role: str):
 
 def reserve_streams(device) -> None:
     """Create the engine's side streams on `device` and put one tiny launch on each, NOW.  The HIP runtime binds a stream to one
-    of its few hardware queues (GPU_MAX_HW_QUEUES, 4) when the stream is first used, least-loaded queue first: called before
-    anything else creates streams -- in particular before torch.distributed / RCCL initialise, which use half a dozen of their
-    own -- the main stream and the three side streams each get a queue to themselves.  Called late, two of them can land on one
-    queue and run one after the other (measured with RCCL initialised first: the second forward chain behind the main stream,
-    cls step 15.0 instead of 10.6 ms)."""
+    of its few hardware queues (GPU_MAX_HW_QUEUES, 4) when the stream is first used -- a new queue while there are fewer than
+    that, the least-loaded one afterwards: called before anything else uses streams -- in particular before torch.distributed /
+    RCCL initialise, which use half a dozen of their own -- the main stream and the two side streams each get a queue to
+    themselves and the fourth is left for RCCL.  Called late, two of them can land on one queue and run one after the other
+    (measured with RCCL initialised first: the second forward chain behind the main stream, cls step 15.0 instead of 10.6 ms)."""
     dev = torch.device(device)
     torch.zeros(1, device=dev)  # (the main stream first)
-    for role in ("aux0", "side", "side2"):
+    for role in ("aux0", "side") + (() if MERGE_AUX_SIDE2 else ("side2",)):
         with torch.cuda.stream(_shared_stream(dev, role)):
             torch.zeros(1, device=dev)
     torch.cuda.synchronize(dev)
@@ -155,7 +159,7 @@ class Kernels:
     def side_stream2(self, device):
         st = getattr(self, "_side2", None)
         if st is None or st.device != device:
-            st = self._side2 = _shared_stream(device, "side2")
+            st = self._side2 = _shared_stream(device, "aux0" if MERGE_AUX_SIDE2 else "side2")
         return st
 
     def _opts(self, wgrad: bool):

@@ -169,7 +169,7 @@ class DataParallel(nn.Module):
                 warnings.warn("ssl4polyp_amd.reserve_streams(device) was not called before torch.distributed initialised: the "
                               "engine's side streams may share a hardware queue with RCCL's or with the main stream and then "
                               "run one after the other (up to 1.4x step time measured).  Call it right after "
-                              "torch.cuda.set_device(), and export GPU_MAX_HW_QUEUES=8 before the process starts.", stacklevel=2)
+                              "torch.cuda.set_device().", stacklevel=2)
             for r in ("vec", "mat"):
                 dist.broadcast(rt.flat.P[r], src=0, group=process_group)
             rt.flat._shadow_versions = None  # force a shadow refresh from the broadcast weights

@@ -58,3 +58,41 @@ def test_device_prefetcher_order_values_and_flips():
     big = [(torch.randint(0, 256, (2, 224, 224, 3), dtype=torch.uint8, generator=g), torch.zeros(2)) for _ in range(2)]
     for imgs, labels in DevicePrefetcher(big, DEV):
         assert m(imgs).shape == (2, 2)
+
+
+def test_device_prefetcher_on_the_engines_side_stream_trains_the_same():
+    """stream="side" (what a data-parallel rank uses: no fifth busy stream beside RCCL's): the staging thread enqueues the copies and
+    the transform on the engine's weight-gradient stream while the main thread enqueues AdamW / weight gradients there -- same batches,
+    same losses and same weights after a few optimizer steps as with a stream of the prefetcher's own."""
+    import ssl4polyp_amd as A
+    from ssl4polyp_amd import engine
+    from ssl4polyp_amd.data import DevicePrefetcher
+    from ssl4polyp_amd.optim import FusedAdamW
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.randint(0, 256, (8, 224, 224, 3), dtype=torch.uint8, generator=g), torch.randint(0, 2, (8,), generator=g))
+               for _ in range(6)]
+
+    def train(mode):
+        torch.manual_seed(5)
+        m = A.ViT_from_MAE(None, True, 2, False, None, embed_dim=128, depth=2, num_heads=2, out_token="cls").to(DEV)
+        opt = FusedAdamW(m, [{"params": list(m.parameters())}], lr=1e-3, overlap_forward=True)
+        pf = DevicePrefetcher(batches, DEV, flip_p=0.5, generator=torch.Generator().manual_seed(2), stream=mode)
+        losses = []
+        for imgs, labels in pf:
+            opt.zero_grad(set_to_none=True)
+            loss = A.supervised_loss(m(imgs), labels)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        used = pf._stream
+        return [float(l) for l in losses], {k: v.detach().float().cpu() for k, v in m.state_dict().items()}, used
+
+    la, sa, st_own = train("own")
+    lb, sb, st_side = train("side")
+    assert st_side is engine._shared_stream(DEV, "side") and st_own is not st_side
+    assert la == lb
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    with pytest.raises(ValueError):
+        DevicePrefetcher(batches, DEV, stream="main")

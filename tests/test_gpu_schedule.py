@@ -63,9 +63,12 @@ def test_side_streams_are_shared_by_every_model_of_the_process():
     from ssl4polyp_amd import engine
     DEV = torch.device("cuda", 0)
     A.reserve_streams(DEV)
-    first = {role: engine._shared_stream(DEV, role) for role in ("aux0", "side", "side2")}
+    first = {role: engine._shared_stream(DEV, role) for role in ("aux0", "side")}
     A.reserve_streams(DEV)
     k1, k2 = engine.Kernels("bf16"), engine.Kernels("fp32")
     for k in (k1, k2):
-        assert k.aux_stream(DEV, 0) is first["aux0"] and k.side_stream(DEV) is first["side"] and k.side_stream2(DEV) is first["side2"]
-    assert len({s.cuda_stream for s in first.values()} | {torch.cuda.current_stream().cuda_stream}) == 4
+        assert k.aux_stream(DEV, 0) is first["aux0"] and k.side_stream(DEV) is first["side"]
+        # the second weight-gradient stream (backward only) is the second forward chain's stream (forward only): main + two
+        # side streams are busy at any time, one hardware queue each, one left for RCCL
+        assert k.side_stream2(DEV) is (first["aux0"] if engine.MERGE_AUX_SIDE2 else engine._shared_stream(DEV, "side2"))
+    assert len({s.cuda_stream for s in first.values()} | {torch.cuda.current_stream().cuda_stream}) == 3
