@@ -194,11 +194,29 @@ def kernel_stats(model, step):
         lay = ("tn" if akm else "n") + ("n" if bkm else "t")
         rec.append((lay if akm else f"{lay}_{EPI.get(epi, epi)}", M, N, K, e0, e1))
 
+    held = []  # (CUs the launch holds, flops, e0, e1) of the grouped weight-gradient launches
+
+    def group_cus(items, K, whole_k):
+        """Workgroups (= CUs: one 128-KB LDS ring each) of this pm_wgrad_group launch: tiles of 256x256 x the library's k-slices."""
+        import ctypes
+        from ssl4polyp_amd import _lib
+        arr = (_lib.WgradItem * len(items))()
+        for j, it in enumerate(items):
+            o, i = it[2].shape
+            arr[j] = _lib.WgradItem(64, o, 64, i, 64, i, o, i, 0, None)
+        tiles, slices = ctypes.c_int(0), ctypes.c_int(0)
+        k.lib.pm_wgrad_group_plan(arr, len(items), K, k.act, None, ctypes.byref(tiles), ctypes.byref(slices))
+        work = tiles.value * (1 if whole_k else max(slices.value, 1))
+        cap = k.GROUP_BLOCKS if (whole_k or slices.value <= 1) else k.GROUP_BLOCKS_SLICED
+        return min(256, work if cap <= 0 else min(work, cap))
+
     def wgrad_group(items, K, **kw):
         e0, e1 = ev2()
         e0.record(); ok = orig["wg"](items, K, **kw); e1.record()
         if ok:
-            rec.append(("wgrad_group", sum(it[2].shape[0] * it[2].shape[1] for it in items), 1, K, e0, e1))
+            mn = sum(it[2].shape[0] * it[2].shape[1] for it in items)
+            rec.append(("wgrad_group", mn, 1, K, e0, e1))
+            held.append((group_cus(items, K, bool(kw.get("whole_k"))), 2.0 * mn * K, e0, e1))
         return ok
 
     def ln_fwd(x, gamma, beta, y, mean, rstd, M, D):
@@ -225,7 +243,7 @@ def kernel_stats(model, step):
     k.wgrad_group = wgrad_group
     try:
         for _ in range(3):
-            rec.clear(); hbm.clear(); att.clear()
+            rec.clear(); hbm.clear(); att.clear(); held.clear()
             step()
         torch.cuda.synchronize()
     finally:
@@ -250,6 +268,13 @@ def kernel_stats(model, step):
         return out
 
     gem = fold([(lay, 2.0 * M * N * K, e0, e1) for lay, M, N, K, e0, e1 in rec], "tflops")
+    if held and "wgrad_group" in gem:
+        # The grouped launches hold a SUBSET of the CUs on purpose (72 + 36 of 256 for a ViT-B block, two launches side by side), so
+        # flops / launch time against the whole chip's peak says how the chip is shared, not how well the kernel runs: also report
+        # the rate on the CUs a launch holds, scaled to 256 CUs
+        cu_s = sum(c / 256.0 * e0.elapsed_time(e1) * 1e-3 for c, _, e0, e1 in held)
+        gem["wgrad_group"]["avg_cus_held"] = round(sum(c for c, *_ in held) / len(held), 1)
+        gem["wgrad_group"]["tflops_on_held_cus_x256"] = round(sum(f for _, f, _, _ in held) / cu_s / 1e12, 1)
     tot_t = sum(v["launches"] * v["avg_us"] for v in gem.values()) * 1e-6
     return gem, fold(hbm, "GBps"), fold(att, "tflops"), tot_t
 
@@ -734,11 +759,14 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
                      "tnn": "gemm_v3_kernel (split-K weight gradient)", "wgrad_group": "wgrad_group_kernel (the dW of a block in two launches, full-K tiles)"}
             roof["kernel"] = {"name": names.get(dom[0], dom[0]), "class": dom[0], **dom[1],
                               "frac": round(dom[1]["tflops"] / peak, 4),
+                              **({"frac_on_held_cus": round(dom[1]["tflops_on_held_cus_x256"] / peak, 4)}
+                                 if "tflops_on_held_cus_x256" in dom[1] else {}),
                               "share_of_gemm_time": round(dom[1]["launches"] * dom[1]["avg_us"] * 1e-6 / max(gt, 1e-12), 3),
                               "note": "the class with the largest summed in-step launch time (HIP events on its own stream); "
                                       "launches of the forward chains / of the dgrad and weight-gradient streams overlap, so "
-                                      "each shares the CUs (the grouped weight gradients take 72 + 36 of the 256 CUs by design; "
-                                      "stand-alone rates: DESIGN.md)"}
+                                      "each shares the CUs (the grouped weight gradients take 72 + 36 of the 256 CUs by design, as two "
+                                      "launches side by side: `frac` prices a launch against the whole chip, `frac_on_held_cus` against "
+                                      "the CUs it holds; stand-alone rates: DESIGN.md)"}
             try:  # PMC traffic of the dominant kernel, from the committed rocprofv3 --pmc passes (profiles/)
                 with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as fh:
                     t = json.load(fh).get(workload, {}).get(dom[0])
