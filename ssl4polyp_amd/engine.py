@@ -122,6 +122,9 @@ class Kernels:
     # of a ViT-B block spread over the whole dgrad chain instead of 108 behind the attention backward (measured, 5 pairs of
     # runs: MAE +0.5 %, cls +0.1 %; gradients bit-identical to the single launch)
     TWO_GROUPS = os.environ.get("PM_TWO_GROUPS", "1") == "1"
+    # bench.py's kernel statistics: the fork / done events of pm_vit_block_bwd carry timestamps, so that the weight-gradient launches
+    # of the one-call-per-block path can be timed in place (fork -> done on an idle side stream = the launch)
+    TIME_BLOCK_EVENTS = False
     gemm_variant = int(os.environ.get("PM_GEMM_VARIANT", "0"))  # pm_gemm_opts.variant: 0 = the dispatcher's heuristics (tuning scripts set it per Kernels object)
 
     # -- scratch buffers: sized by the library's own queries (pm_gemm_workspace_bytes / pm_workspace_bytes), cached per
@@ -479,14 +482,15 @@ class BlockStack:
             items[j] = _lib.WgradItem(64, n_out, 64, n_in, 64, n_in, n_out, n_in, 0, 64 if bias else None)  # (sizes only)
         need = k._need(("groupws", M, k.act, D, Hd), lambda: k.lib.pm_wgrad_group_workspace_bytes(items, 4, M, k.act))
         ws_group = k._scratch("_ws_group", need, dx.device) if need else None
-        ev_fork, ev_done = torch.cuda.Event(), torch.cuda.Event()
+        mk = lambda: torch.cuda.Event(enable_timing=bool(k.TIME_BLOCK_EVENTS))
+        ev_fork, ev_done = mk(), mk()
         ev_fork.record(main)   # (materialises the hipEvent_t handles; re-recorded by every call)
         ev_done.record(main)
         two = not need and k.two_launch_group(M, ((D, Hd), (Hd, D), (D, D), (3 * D, D)))
         ev_fork2 = ev_done2 = side2 = None
         if two:
             side2 = k.side_stream2(dx.device)
-            ev_fork2, ev_done2 = torch.cuda.Event(), torch.cuda.Event()
+            ev_fork2, ev_done2 = mk(), mk()
             ev_fork2.record(main)
             ev_done2.record(main)
         desc = _lib.BlockBwdDesc(
@@ -574,7 +578,7 @@ class BlockStack:
                        int(accumulate("mlp.fc1.weight", i)) << 2 | int(accumulate("mlp.fc2.weight", i)) << 3)
                 key = (dx.data_ptr(), dx_act.data_ptr(), xin.data_ptr(), gr["attn.qkv.weight"].data_ptr(),
                        p["attn.qkv.weight"].data_ptr(), gr["norm1.weight"].data_ptr(),
-                       below_bias.data_ptr() if below_bias is not None else 0, acc, k.gemm_variant, k.GROUP_BLOCKS, k.GROUP_BLOCKS_SLICED, k.TWO_GROUPS,
+                       below_bias.data_ptr() if below_bias is not None else 0, acc, k.gemm_variant, k.GROUP_BLOCKS, k.GROUP_BLOCKS_SLICED, k.TWO_GROUPS, k.TIME_BLOCK_EVENTS,
                        ptr_of(k.__dict__.get("_ws_ln")), ptr_of(k.__dict__.get("_ws_group")))  # (scratch is replaced when it grows)
                 ent = bcache.get(i)
                 if ent is None or ent[0] != key:
