@@ -40,9 +40,10 @@ FINETUNE_GFLOP = {"none": FWD_GFLOP_PER_IMG, "head+1": FWD_GFLOP_PER_IMG + 2 * B
                   "head+2": FWD_GFLOP_PER_IMG + 4 * BLOCK_FWD_GFLOP, "full": 105.38}
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense bf16 MFMA / f32 MFMA
 PEAK_HBM_GBPS = 8000.0                         # MI355X_MICROARCH.md: HBM3E
-# AdamW on the side stream beside the next forward: +0.5..1 % on the fine-tune step (its forward is MFMA-bound), -1.3 % on the
-# MAE step (its encoder forward on 50 tokens is short and HBM-hungry itself); PM_OVERLAP_ADAMW=0/1 forces either
-OVERLAP_ADAMW = {"cls": os.environ.get("PM_OVERLAP_ADAMW", "1") != "0", "mae": os.environ.get("PM_OVERLAP_ADAMW", "0") != "0"}
+# AdamW on the side stream beside the next forward: +0.5 % on the fine-tune step and +0.6 % on the MAE step under the final stream
+# layout (scratch/r3_exp31.sh; with a stream set per model and the update sharing a hardware queue it cost the MAE step 1.3 %);
+# PM_OVERLAP_ADAMW=0/1 forces either
+OVERLAP_ADAMW = {"cls": os.environ.get("PM_OVERLAP_ADAMW", "1") != "0", "mae": os.environ.get("PM_OVERLAP_ADAMW", "1") != "0"}
 MAE_IT_PER_EPOCH = 390  # ~100 k unlabelled frames / 256 per step
 WORKLOAD_NAME = {"cls": "ViT-B/16 classification fine-tune", "mae": "MAE pre-train ViT-B/16 mask 0.75"}
 
