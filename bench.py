@@ -683,6 +683,7 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
     # settles into a slower phase) is reported beside the mean the metric is computed from
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    t0_unix = time.time()
     marks[0].record()
     if host_input:
         for i, (im, lb) in enumerate(host_feed(args.steps)):
@@ -697,6 +698,7 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    t1_unix = time.time()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -810,6 +812,7 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
             roof["gemm_share_of_step"] = round(gt / (dt / args.steps), 3)
         rec = {"value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),
                "host_enqueue_ms_per_step": round(t_enq * 1e3, 3), "step_ms": step_ms, "preheat_steps": preheat_steps,
+               "timed_region_unix": [round(t0_unix, 3), round(t1_unix, 3)],  # (for scratch/telemetry.py traces)
                "config": {"workload": WORKLOAD_NAME[workload] + f", bs={batch}/GPU, 224^2, AdamW, random init"
                                       + (f", finetune mode {finetune_mode} (finetune.py:49-91)" if workload == "cls" else ""),
                           "global_batch": batch * world, "parallelism": f"dp{world}" + ("+forced world-1 RCCL all-reduces" if ddp.sync is not None and world == 1 else ""),

@@ -12,8 +12,13 @@
  *     allocates, frees, retains pointers or synchronises; every launch goes to `stream`
  *     (a hipStream_t passed as void*).
  *   - return 0 on success, negative pm_status otherwise; no C++ exceptions cross the ABI.
- *   - dtype codes: PM_F32 = 0, PM_BF16 = 1.  "act" tensors (activations between kernels) use the
- *     precision mode's activation type: bf16 in PM_BF16 mode, f32 in PM_F32 mode.
+ *   - dtype codes: PM_F32 = 0, PM_BF16 = 1, PM_F16 = 2.  "act" tensors (activations between kernels) use the
+ *     precision mode's activation type: bf16 in PM_BF16 mode, IEEE half in PM_F16 mode, f32 in PM_F32 mode.
+ *     PM_F16 is the reference's own AMP arithmetic (torch.cuda.amp.autocast runs every matmul in fp16 with f32
+ *     accumulation: train_classification.py:4527-4546, engine_pretrain.py:52): same kernels, same MFMA rate
+ *     (v_mfma_f32_32x32x16_f16), 11 significant bits per operand instead of 8.  The backward operands are fp16 too
+ *     (an MFMA takes one type for both operands), so the caller scales the loss as the reference's GradScaler does;
+ *     every backward entry point is linear in its incoming gradient and passes inf / nan through.
  *   - matrices are row-major with explicit leading dimensions in ELEMENTS.
  */
 #ifndef POLYPMAE_H
@@ -26,7 +31,7 @@ extern "C" {
 #endif
 
 enum pm_status { PM_OK = 0, PM_EINVAL = -1, PM_ESHAPE = -2, PM_EARCH = -3, PM_ELAUNCH = -4, PM_EALIGN = -5 };
-enum pm_dtype { PM_F32 = 0, PM_BF16 = 1 };
+enum pm_dtype { PM_F32 = 0, PM_BF16 = 1, PM_F16 = 2 };
 
 /* epilogue selector of pm_gemm (what happens to acc = op(A)*op(B) before it is stored) */
 enum pm_epilogue {

@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--workload", choices=["cls", "mae"], default="cls")
     ap.add_argument("--threads", type=int, default=len(os.sched_getaffinity(0)))
     ap.add_argument("--variants", default="all")
+    ap.add_argument("--family", choices=["bf16", "fp16"], default="bf16",
+                    help="bf16: one bf16 rounding point off at a time (round 3); fp16: the 16-bit type of the forward / backward "
+                         "operands and the loss scale (round 4: which 16-bit mode meets SURVEY 8-d as written)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
@@ -89,9 +92,10 @@ def main():
         return rec
 
     recs = []
-    names = list(S.VARIANTS) if args.variants == "all" else [n for n in S.VARIANTS if any(t in n for t in args.variants.split(","))]
+    table = S.VARIANTS if args.family == "bf16" else S.FP16_VARIANTS
+    names = list(table) if args.variants == "all" else [n for n in table if any(t in n for t in args.variants.split(","))]
     for name in names:
-        rnd = S.VARIANTS[name]
+        rnd = table[name]
         if cls:
             recs.append(report(name, run(lambda p: S.vit_classify(p, imgs, cfg, rnd))))
         else:
@@ -100,7 +104,8 @@ def main():
     def autocast(p):
         with torch.autocast("cpu", dtype=torch.bfloat16):
             return O.vit_classify(p, imgs, cfg) if cls else O.mae_forward(p, imgs, noise, cfg)
-    recs.append(report("torch.autocast(cpu, bf16) of the oracle (yardstick)", run(autocast)))
+    if args.family == "bf16":
+        recs.append(report("torch.autocast(cpu, bf16) of the oracle (yardstick)", run(autocast)))
     if args.out:
         with open(args.out, "w") as fh:
             json.dump({"workload": args.workload, "batch": args.batch, "init": args.init, "pos_weight": pw, "records": recs}, fh, indent=1)

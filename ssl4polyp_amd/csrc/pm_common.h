@@ -22,6 +22,8 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -29,10 +31,11 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
-// A 16-byte operand fragment: 8 bf16 (one 32x32x16 MFMA) or 4 f32 (four 32x32x2 MFMAs).
+// A 16-byte operand fragment: 8 bf16 or 8 f16 (one 32x32x16 MFMA) or 4 f32 (four 32x32x2 MFMAs).
 union Frag16 {
   u32x4 u;
   bf16x8 h;
+  f16x8 g;
   f32x4 f;
 };
 
@@ -59,18 +62,44 @@ template <> struct ElemTraits<__bf16> {
   static constexpr int kDtype = PM_BF16;
   static constexpr int kPer16B = 8;
 };
+template <> struct ElemTraits<_Float16> {
+  static constexpr int kDtype = PM_F16;
+  static constexpr int kPer16B = 8;
+};
 template <> struct ElemTraits<float> {
   static constexpr int kDtype = PM_F32;
   static constexpr int kPer16B = 4;
 };
+template <typename T> struct IsHalf { static constexpr bool value = false; };
+template <> struct IsHalf<_Float16> { static constexpr bool value = true; };
+
+// The activation type of a dtype code, as a compile-time type inside `...`:  PM_DISPATCH_ACT(dtype, T, launch<T>(...));
+// an unknown code returns PM_EINVAL from the enclosing function.
+#define PM_DISPATCH_ACT(dtype, T, ...)                         \
+  do {                                                         \
+    if ((dtype) == PM_BF16) { using T = __bf16; __VA_ARGS__; }  \
+    else if ((dtype) == PM_F16) { using T = _Float16; __VA_ARGS__; } \
+    else if ((dtype) == PM_F32) { using T = float; __VA_ARGS__; }   \
+    else return PM_EINVAL;                                     \
+  } while (0)
+// the same over the two 16-bit types only
+#define PM_DISPATCH_16(dtype, T, ...)                          \
+  do {                                                         \
+    if ((dtype) == PM_BF16) { using T = __bf16; __VA_ARGS__; }  \
+    else if ((dtype) == PM_F16) { using T = _Float16; __VA_ARGS__; } \
+    else return PM_EINVAL;                                     \
+  } while (0)
 
 // acc[reg -> A-row][lane -> B-col] += A(16B frag) x B(16B frag).
-// bf16: one v_mfma_f32_32x32x16_bf16 (lane (r,h) holds k = 8h..8h+7 of row/col r).
+// bf16: one v_mfma_f32_32x32x16_bf16 (lane (r,h) holds k = 8h..8h+7 of row/col r); f16: v_mfma_f32_32x32x16_f16, same map,
+//       same rate (precision mode "fp16": 11 significant bits per operand instead of 8).
 // f32 : four v_mfma_f32_32x32x2_f32; element e of lane half h stands for k = 4*(2j+h)+e in BOTH
 //       operands, so any k permutation is consistent (exact f32 fma chain).
 template <typename T>
 __device__ __forceinline__ f32x16 mfma16B(const Frag16& a, const Frag16& b, f32x16 acc) {
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (IsHalf<T>::value) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.g, b.g, acc, 0, 0, 0);
+  } else if constexpr (sizeof(T) == 2) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
   } else {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.f[0], b.f[0], acc, 0, 0, 0);
@@ -80,6 +109,24 @@ __device__ __forceinline__ f32x16 mfma16B(const Frag16& a, const Frag16& b, f32x
     return acc;
   }
 }
+// 16 x 16 x 32 form of the 16-bit types (4 accumulator registers)
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16x16(const Frag16& a, const Frag16& b, f32x4 acc) {
+  if constexpr (IsHalf<T>::value) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.g, b.g, acc, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+// element j of a 16-bit fragment <- f32 (the accumulator fed back as an MFMA operand)
+template <typename T> __device__ __forceinline__ void frag_set(Frag16& f, int j, float v) {
+  if constexpr (IsHalf<T>::value) f.g[j] = (_Float16)v;
+  else f.h[j] = (__bf16)v;
+}
+template <typename T> __device__ __forceinline__ float frag_get(const Frag16& f, int j) {
+  if constexpr (IsHalf<T>::value) return (float)f.g[j];
+  else if constexpr (sizeof(T) == 2) return (float)f.h[j];
+  else return f.f[j];
+}
+// two 1.0 of the 16-bit type in one dword
+template <typename T> __device__ __forceinline__ unsigned ones2() { return IsHalf<T>::value ? 0x3C003C00u : 0x3F803F80u; }
 
 // Row index (within a 32x32 accumulator tile) of register `reg` for lane half `h`.
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
@@ -94,7 +141,8 @@ template <typename T> __device__ __forceinline__ f32x4 load4(const T* p) {
   if constexpr (sizeof(T) == 4) {
     return *reinterpret_cast<const f32x4*>(p);
   } else {
-    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    typedef T __attribute__((ext_vector_type(4))) V4;
+    const V4 v = *reinterpret_cast<const V4*>(p);
     f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     return r;
   }
@@ -103,22 +151,24 @@ template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v) {
   if constexpr (sizeof(T) == 4) {
     *reinterpret_cast<f32x4*>(p) = v;
   } else {
-    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-    *reinterpret_cast<bf16x4*>(p) = o;
+    typedef T __attribute__((ext_vector_type(4))) V4;
+    const V4 o = {(T)v[0], (T)v[1], (T)v[2], (T)v[3]};
+    *reinterpret_cast<V4*>(p) = o;
   }
 }
 
 // 8 consecutive bf16 as one 16-B access (a wave store instruction costs the CU's store path ~64 cycles whatever
 // its width: 16 B per lane halves the epilogue's store time against 8 B per lane)
-__device__ __forceinline__ void load8_bf16(const __bf16* p, f32x4& lo, f32x4& hi) {
-  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+template <typename T> __device__ __forceinline__ void load8_16(const T* p, f32x4& lo, f32x4& hi) {
+  typedef T __attribute__((ext_vector_type(8))) V8;
+  const V8 v = *reinterpret_cast<const V8*>(p);
   lo = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   hi = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
 }
-__device__ __forceinline__ void store8_bf16(__bf16* p, f32x4 lo, f32x4 hi) {
-  const bf16x8 o = {(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3],
-                    (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]};
-  *reinterpret_cast<bf16x8*>(p) = o;
+template <typename T> __device__ __forceinline__ void store8_16(T* p, f32x4 lo, f32x4 hi) {
+  typedef T __attribute__((ext_vector_type(8))) V8;
+  const V8 o = {(T)lo[0], (T)lo[1], (T)lo[2], (T)lo[3], (T)hi[0], (T)hi[1], (T)hi[2], (T)hi[3]};
+  *reinterpret_cast<V8*>(p) = o;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -208,6 +208,7 @@ __device__ __forceinline__ void mma_kstep(const char* bx, const char* bw, int wm
 // operand registers feed TWO v_mfma_f32_16x16x32_bf16 (same FLOPs, same pipe cycles: 2 x 16 = 32) on two quarters of the
 // accumulator -- the results are WRONG (the fragment maps differ), the build only answers "what clock does the chip hold on
 // this k-loop with the other MFMA shape" (MI355X_MICROARCH.md, DVFS give-back item 7).  Never shipped.
+template <typename E>
 __device__ __forceinline__ void ring_mfma(const Frag16& a, const Frag16& b, f32x16& acc, int kk) {
 #ifdef PM_MFMA16_TIMING
   f32x4 lo = {acc[8 * kk], acc[8 * kk + 1], acc[8 * kk + 2], acc[8 * kk + 3]};
@@ -221,7 +222,7 @@ __device__ __forceinline__ void ring_mfma(const Frag16& a, const Frag16& b, f32x
   }
 #else
   (void)kk;
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+  acc = mfma16B<E>(a, b, acc);
 #endif
 }
 
@@ -250,10 +251,14 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int epi, long off, 
       const f32x4 pre = load4<T>(reinterpret_cast<const T*>(a.aux) + off);
       v *= gelu_erf_grad4(pre);
     }
-    if (a.c_dtype == PM_F32)
+    if (a.c_dtype == PM_F32) {
       store4<float>(reinterpret_cast<float*>(a.C) + off, v);
-    else
-      store4<__bf16>(reinterpret_cast<__bf16*>(a.C) + off, v);
+    } else if constexpr (sizeof(T) == 2) {
+      store4<T>(reinterpret_cast<T*>(a.C) + off, v);  // (a 16-bit C has the operands' type: checked by the dispatcher)
+    } else {
+      if (a.c_dtype == PM_F16) store4<_Float16>(reinterpret_cast<_Float16*>(a.C) + off, v);
+      else store4<__bf16>(reinterpret_cast<__bf16*>(a.C) + off, v);
+    }
   }
 }
 
@@ -261,7 +266,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int epi, long off, 
 // issued before the first store, so the loads overlap instead of forming one load -> store latency chain per vector
 // (stamped on the 256x256 tile: 25.6k cycles per wave for 32 dependent chains).  off[] must be valid addresses (the
 // caller clamps rows / columns beyond M / N); ok[] gates the stores.
-template <int NV>
+template <typename E, int NV>
 __device__ __forceinline__ void epilogue_batch(const GemmArgs& a, int epi, const long (&off)[NV], const bool (&ok)[NV],
                                                f32x4 (&v)[NV]) {
   if (epi == PM_EPI_RESIDUAL || epi == PM_EPI_ACCUM) {
@@ -277,14 +282,14 @@ __device__ __forceinline__ void epilogue_batch(const GemmArgs& a, int epi, const
   if (epi == PM_EPI_DGELU) {
     f32x4 pre[NV];
 #pragma unroll
-    for (int e = 0; e < NV; ++e) pre[e] = load4<__bf16>(reinterpret_cast<const __bf16*>(a.aux) + off[e]);
+    for (int e = 0; e < NV; ++e) pre[e] = load4<E>(reinterpret_cast<const E*>(a.aux) + off[e]);
 #pragma unroll
     for (int e = 0; e < NV; ++e) v[e] *= gelu_erf_grad4(pre[e]);
   } else if (epi == PM_EPI_GELU) {
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
-      if (ok[e]) store4<__bf16>(reinterpret_cast<__bf16*>(a.aux) + off[e], v[e]);
-      v[e] = gelu_erf4(round_through<__bf16>(v[e]));  // what backward will see
+      if (ok[e]) store4<E>(reinterpret_cast<E*>(a.aux) + off[e], v[e]);
+      v[e] = gelu_erf4(round_through<E>(v[e]));  // what backward will see
     }
   }
   if (a.c_dtype == PM_F32) {
@@ -294,18 +299,18 @@ __device__ __forceinline__ void epilogue_batch(const GemmArgs& a, int epi, const
   } else {
 #pragma unroll
     for (int e = 0; e < NV; ++e)
-      if (ok[e]) store4<__bf16>(reinterpret_cast<__bf16*>(a.C) + off[e], v[e]);
+      if (ok[e]) store4<E>(reinterpret_cast<E*>(a.C) + off[e], v[e]);
   }
 }
 
-// 8 consecutive n per vector, act-typed (bf16) C, epilogues STORE / GELU / DGELU: 16-B accesses.
-template <int NV>
+// 8 consecutive n per vector, act-typed (16-bit) C, epilogues STORE / GELU / DGELU: 16-B accesses.
+template <typename E, int NV>
 __device__ __forceinline__ void epilogue_batch8(const GemmArgs& a, int epi, const long (&off)[NV], const bool (&ok)[NV],
                                                 f32x4 (&lo)[NV], f32x4 (&hi)[NV]) {
   if (epi == PM_EPI_DGELU) {
     f32x4 plo[NV], phi[NV];
 #pragma unroll
-    for (int u = 0; u < NV; ++u) load8_bf16(reinterpret_cast<const __bf16*>(a.aux) + off[u], plo[u], phi[u]);
+    for (int u = 0; u < NV; ++u) load8_16<E>(reinterpret_cast<const E*>(a.aux) + off[u], plo[u], phi[u]);
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       lo[u] *= gelu_erf_grad4(plo[u]);
@@ -314,14 +319,14 @@ __device__ __forceinline__ void epilogue_batch8(const GemmArgs& a, int epi, cons
   } else if (epi == PM_EPI_GELU) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      if (ok[u]) store8_bf16(reinterpret_cast<__bf16*>(a.aux) + off[u], lo[u], hi[u]);
-      lo[u] = gelu_erf4(round_through<__bf16>(lo[u]));  // gelu of the value backward will see (the bf16-rounded pre-activation)
-      hi[u] = gelu_erf4(round_through<__bf16>(hi[u]));
+      if (ok[u]) store8_16<E>(reinterpret_cast<E*>(a.aux) + off[u], lo[u], hi[u]);
+      lo[u] = gelu_erf4(round_through<E>(lo[u]));  // gelu of the value backward will see (the rounded pre-activation)
+      hi[u] = gelu_erf4(round_through<E>(hi[u]));
     }
   }
 #pragma unroll
   for (int u = 0; u < NV; ++u)
-    if (ok[u]) store8_bf16(reinterpret_cast<__bf16*>(a.C) + off[u], lo[u], hi[u]);
+    if (ok[u]) store8_16<E>(reinterpret_cast<E*>(a.C) + off[u], lo[u], hi[u]);
 }
 
 // exchange between lane l and lane l+32: afterwards the low half-wave holds (x of lane l, x of lane l+32) in (x, y)
@@ -618,7 +623,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // shape: qkv 55.5 -> 48.8 us, fc1+GELU 102 -> 96).  Built for the forward kernels whose both operands are k-normal, on the
 // ping-pong loop with the LDS-staged epilogue (the accumulator layout changes: lane = m % 16, registers = 4 consecutive n).
 template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, bool DIRECT, bool PP, bool XK, int NW, bool SWP,
-          bool XSUM = false, bool M16 = false>
+          bool XSUM = false, bool M16 = false, typename E = __bf16>
 __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const int split_idx) {
   static_assert(!M16 || (PP && !DIRECT && !XK && !WK && !XSUM && !SWP && NW == 8), "16x16x32 variant: k-normal ping-pong, staged epilogue");
   constexpr int TM = BM_ / WM, TN = BN_ / WN;      // per-wave tile
@@ -637,7 +642,8 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
   const int wm = wave / WN, wn = wave % WN;
 #ifdef PM_GEMM_STAMP
   const unsigned long long stamp_entry = __builtin_readcyclecounter();
-  unsigned long long stamp_loop_end = 0;
+  const unsigned long long stamp_entry_rt = __builtin_amdgcn_s_memrealtime();  // 100 MHz: clock = d(cycles) / d(realtime) x 100 MHz
+  unsigned long long stamp_loop_end = 0, stamp_loop_end_rt = 0;
   auto stamp_finish = [&]() {
     const unsigned long long t_issued = __builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -645,6 +651,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
     if (a.stamps && lane == 0 && blockIdx.y == 0) {
       unsigned long long* o = a.stamps + ((long)blockIdx.x * NW + wave) * 16;
       o[8] = stamp_entry; o[9] = stamp_loop_end; o[10] = t_issued; o[11] = t_acked;
+      o[12] = stamp_entry_rt; o[13] = stamp_loop_end_rt;
     }
   };
 #endif
@@ -689,7 +696,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
   if constexpr (XSUM) {
     do_xsum = a.xsum != nullptr && tn == 0 && wn == 0;
     const bool one = lane == 0 || lane == 32 || lane == 17 || lane == 49;
-    const unsigned v = one ? 0x3F803F80u : 0u;  // two bf16 1.0
+    const unsigned v = one ? ones2<E>() : 0u;  // two 1.0 of the operand type
     ones_sel.u = u32x4{v, v, v, v};
 #pragma unroll
     for (int j = 0; j < MT; ++j) xs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -727,14 +734,14 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
       for (int i = 0; i < NTL; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j)
-          ring_mfma(fw[kk][i], fx[kk][j], acc[i][j], kk);
+          ring_mfma<E>(fw[kk][i], fx[kk][j], acc[i][j], kk);
     if constexpr (XSUM) {
       if (do_xsum) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
           for (int j = 0; j < MT; ++j)
-            xs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_sel.h, fx[kk][j].h, xs[j], 0, 0, 0);
+            xs[j] = mfma16x16<E>(ones_sel, fx[kk][j], xs[j]);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -812,7 +819,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
 #pragma unroll
       for (int m = 0; m < NMF; ++m) {
         const int kk = m / (NTL * MT), i = (m / MT) % NTL, j = m % MT;
-        ring_mfma(cw[kk][i], cx[kk][j], acc[i][j], kk);
+        ring_mfma<E>(cw[kk][i], cx[kk][j], acc[i][j], kk);
         __builtin_amdgcn_sched_barrier(0);
         if (m < NR && rd) read_one(t + 1, m, nw, nx);
         if ((m % PER) == 1 && m / PER < G && ld) piece(t + AHEAD, m / PER);
@@ -827,7 +834,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
           for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int j = 0; j < MT; ++j)
-              xs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones_sel.h, cx[kk][j].h, xs[j], 0, 0, 0);
+              xs[j] = mfma16x16<E>(ones_sel, cx[kk][j], xs[j]);
         }
       }
 #ifdef PM_GEMM_STAMP
@@ -949,7 +956,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
         for (int i = 0; i < NT16; ++i)
 #pragma unroll
           for (int j = 0; j < MT16; ++j)
-            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gw[i].h, gx[j].h, acc16[i][j], 0, 0, 0);
+            acc16[i][j] = mfma16x16<E>(gw[i], gx[j], acc16[i][j]);
         __builtin_amdgcn_s_setprio(0);
       } else {
         mma_all(fw, fx);
@@ -971,6 +978,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
   }
 #ifdef PM_GEMM_STAMP
   stamp_loop_end = __builtin_readcyclecounter();
+  stamp_loop_end_rt = __builtin_amdgcn_s_memrealtime();
 #endif
   if constexpr (XSUM) {
     if (do_xsum && lane < 16) {  // one wave per row range: plain read-modify-write, fixed order
@@ -987,7 +995,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
   if constexpr (DIRECT) {
     // straight from registers (lane = row m, register quad = 4 consecutive n): no LDS, no block barrier -- the
     // stores drain while the CU's other resident block keeps the MFMA pipe busy
-    if (a.c_dtype == PM_BF16 && epi != PM_EPI_RESIDUAL && epi != PM_EPI_ACCUM && (a.N & 7) == 0 && (a.ldc & 7) == 0) {
+    if (a.c_dtype != PM_F32 && epi != PM_EPI_RESIDUAL && epi != PM_EPI_ACCUM && (a.N & 7) == 0 && (a.ldc & 7) == 0) {
       // act-typed output: lanes l and l+32 (same row m, columns 8g+4h) trade 4-vectors so that each holds 8
       // consecutive columns -> 16-B stores
       constexpr int NV8 = NTL * 2;
@@ -1033,7 +1041,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
             off[p] = row + noff8[e];
             ok[p] = mok && nok8[e];
           }
-          epilogue_batch8<2>(a, epi, off, ok, lo, hi);
+          epilogue_batch8<E, 2>(a, epi, off, ok, lo, hi);
         }
       }
 #ifdef PM_GEMM_STAMP
@@ -1077,7 +1085,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
           ok[g] = mok && nok[e];
           v[g] = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + bv[e];
         }
-        epilogue_batch<4>(a, epi, off, ok, v);
+        epilogue_batch<E, 4>(a, epi, off, ok, v);
       }
     }
 #ifdef PM_GEMM_STAMP
@@ -1115,7 +1123,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
       }
       __builtin_amdgcn_wave_barrier();
       const int mw = m0 + wm * TM + mh * 64, nw = n0 + wn * TN + nh * 64;
-      if (a.c_dtype == PM_BF16 && epi != PM_EPI_RESIDUAL && epi != PM_EPI_ACCUM && (a.N & 7) == 0 && (a.ldc & 7) == 0) {
+      if (a.c_dtype != PM_F32 && epi != PM_EPI_RESIDUAL && epi != PM_EPI_ACCUM && (a.N & 7) == 0 && (a.ldc & 7) == 0) {
         // act-typed output: 8 columns per lane -> 16-B stores (8 rows x 128 B per wave instruction)
         const int c8 = (lane & 7) * 8, n8 = nw + c8;
         const bool nok8 = n8 < a.N;
@@ -1139,7 +1147,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
             lo[u] = *reinterpret_cast<const f32x4*>(st + ml * STAGE_ROW + c8 * 4) + b0;
             hi[u] = *reinterpret_cast<const f32x4*>(st + ml * STAGE_ROW + c8 * 4 + 16) + b1;
           }
-          epilogue_batch8<4>(a, epi, off, ok, lo, hi);
+          epilogue_batch8<E, 4>(a, epi, off, ok, lo, hi);
         }
         __builtin_amdgcn_wave_barrier();
         continue;
@@ -1162,7 +1170,7 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
           off[u] = (long)(m < a.M ? m : a.M - 1) * a.ldc + ncl;
           v[u] = *reinterpret_cast<const f32x4*>(st + ml * STAGE_ROW + c4 * 4) + bv;
         }
-        epilogue_batch<4>(a, epi, off, ok, v);
+        epilogue_batch<E, 4>(a, epi, off, ok, v);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -1173,9 +1181,9 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
 }
 
 template <int BM_, int BN_, int WM, int WN, bool WK, int STAGES, int MINW, bool DIRECT, bool PP, bool XK = false, int NW = 8,
-          bool SWP = false, bool M16 = false>
+          bool SWP = false, bool M16 = false, typename E = __bf16>
 __global__ __launch_bounds__(NW * 64, MINW) void gemm_v3_kernel(GemmArgs a) {
-  gemm_v3_tile<BM_, BN_, WM, WN, WK, STAGES, DIRECT, PP, XK, NW, SWP, false, M16>(a, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y);
+  gemm_v3_tile<BM_, BN_, WM, WN, WK, STAGES, DIRECT, PP, XK, NW, SWP, false, M16, E>(a, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1209,9 +1217,12 @@ struct WgradGroupArgs {
   int ksteps_split;
   int auto_order;     // per-problem tile order: the shorter side fastest (0: row by row, the A/B baseline)
   long total_vec, bias_begin, bias_total;  // reduce launch: float4 items, then bias rows
+#ifdef PM_GEMM_STAMP
+  unsigned long long* stamps;
+#endif
 };
 
-template <int BM_, int BN_, int WM, int WN>
+template <int BM_, int BN_, int WM, int WN, typename E = __bf16>
 __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroupArgs g) {
   // gridDim.x workgroups (a multiple of 8, or the whole work list) walk the (k-slice, tile) items t = blockIdx.x,
   // + gridDim.x, ...: the caller chooses how many CUs the weight-gradient stream takes from the dgrad chain beside it.
@@ -1241,11 +1252,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroupArgs g) {
       a.xsum = pr.dbias ? pr.bias_part + (long)slice * pr.M : nullptr; a.xsum_store = 1;
     }
 #ifdef PM_GEMM_STAMP
-    a.stamps = nullptr;
+    a.stamps = g.stamps;  // (rows of the block index: the caller hands a region of its own to the grouped launches)
 #endif
     // (the software-pipelined loop needs 254 VGPRs without the row sums: with them it spills 73 and runs 1.5x slower;
     //  without them, bias gradients by separate column-sum passes, it equals this loop with the row sums inside)
-    gemm_v3_tile<BM_, BN_, WM, WN, true, 4, true, true, true, 8, false, true>(a, tile - pr.tile_begin, slice);
+    gemm_v3_tile<BM_, BN_, WM, WN, true, 4, true, true, true, 8, false, true, false, E>(a, tile - pr.tile_begin, slice);
     __syncthreads();  // every wave is done with the LDS ring before the next tile's first stages are issued
   }
 }
@@ -1286,18 +1297,19 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgradGroupArgs 
 }
 
 // forward GEMM on the 16x16x32 loop (both operands k-normal): 256 x 256 ping-pong, LDS-staged epilogue
+template <typename E>
 int launch_v3_m16(GemmArgs a, hipStream_t s) {
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.N + 255) / 256;
   constexpr int ring = 4 * 512 * 64, stage = 8 * V3_STAGE_WAVE;
   const size_t lds = ring > stage ? ring : stage;
-  auto kern = gemm_v3_kernel<256, 256, 2, 4, false, 4, 2, false, true, false, 8, false, true>;
+  auto kern = gemm_v3_kernel<256, 256, 2, 4, false, 4, 2, false, true, false, 8, false, true, E>;
   PM_ALLOW_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
   return pm_check_launch();
 }
 
-template <int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, int NW = 8, bool SWP = false>
+template <typename E, int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bool DIRECT, bool PP = false, int NW = 8, bool SWP = false>
 int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   a.tiles_m = (a.M + BM_ - 1) / BM_;
   a.tiles_n = (a.N + BN_ - 1) / BN_;
@@ -1306,11 +1318,11 @@ int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   const size_t lds = ring > stage ? ring : stage;
   const dim3 grid(a.tiles_m * a.tiles_n), block(NW * 64);
   if (wk) {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP, false, NW, SWP>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, STAGES, MINW, DIRECT, PP, false, NW, SWP, false, E>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else {
-    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP, false, NW, SWP>;
+    auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, false, STAGES, MINW, DIRECT, PP, false, NW, SWP, false, E>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   }
@@ -1318,13 +1330,13 @@ int launch_v3(GemmArgs a, int wk, hipStream_t s) {
 }
 
 // wgrad shape (both operands k-major, K = #tokens): 256x128 ping-pong ring kernel, direct epilogue, split-K slabs
-template <int BM_, int BN_, int WM, int WN, bool SWP>
+template <typename E, int BM_, int BN_, int WM, int WN, bool SWP>
 int launch_v3_wgrad(GemmArgs a, hipStream_t s) {
   a.tiles_m = (a.M + BM_ - 1) / BM_;
   a.tiles_n = (a.N + BN_ - 1) / BN_;
   constexpr int ring = 4 * (BM_ + BN_) * 64;
   const dim3 grid(a.tiles_m * a.tiles_n, a.split_k), block(512);
-  auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, 4, 2, true, !SWP, true, 8, SWP>;
+  auto kern = gemm_v3_kernel<BM_, BN_, WM, WN, true, 4, 2, true, !SWP, true, 8, SWP, false, E>;
   PM_ALLOW_LDS(kern, ring);
   hipLaunchKernelGGL(kern, grid, block, ring, s, a);
   return pm_check_launch();
@@ -1369,6 +1381,31 @@ int launch_glds(const GemmArgs& a, int xk, int wk, hipStream_t s) {
   return pm_check_launch();
 }
 
+// the ring-kernel variants the dispatcher chooses from (cfg: see gemm_dispatch), per 16-bit operand type
+template <typename E>
+int launch_v3_cfg(int cfg, const GemmArgs& a, int b_kmajor, hipStream_t s) {
+  switch (cfg) {
+    case 6: return launch_v3<E, 256, 256, 2, 4, 4, 2, true>(a, b_kmajor, s);          // plain ring loop, register epilogue
+    case 8: return launch_v3<E, 256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);   // ping-pong, LDS-staged epilogue
+    case 40: if (!b_kmajor) return launch_v3_m16<E>(a, s);                            // the same on v_mfma_f32_16x16x32_bf16
+             return launch_v3<E, 256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);
+    case 9: return launch_v3<E, 256, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);    // ping-pong, register epilogue
+    case 10: return launch_v3<E, 192, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);   // 192-row tiles: finer M granularity
+    // software-pipelined loop (fragment reads and DMA issue between the wave's own MFMAs)
+    case 24: return launch_v3<E, 256, 256, 2, 4, 4, 2, false, false, 8, true>(a, b_kmajor, s);
+    case 25: return launch_v3<E, 256, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);
+    case 26: return launch_v3<E, 192, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);
+    // Measured and no longer instantiated (the template still admits them):
+    //   two 4-wave blocks per CU   launch_v3<E, 128, 256, 2, 2, 3, 2, false, false, 4, true>   slower on every shape
+    //   two 8-wave blocks per CU   launch_v3<E, 256, 128, 4, 2, 3, 4, true> / <128, 256, 2, 4, 3, 4, true>: <= 128 VGPRs, 100-150
+    //                              spills, 85 instead of 128 FLOP per LDS-fill byte: 1.7x slower
+    //   one wave per SIMD          launch_v3<E, 256, 256, 2, 2, 4, 1, true, false, 4, true>: 128x128 per wave, 512 VGPRs, 2/3 of the
+    //                              LDS reads per FLOP: equals the 8-wave loop on long-K dgrads (decoder dfc1 1.0 PFLOP/s both),
+    //                              loses 5-30 % wherever prologue / epilogue matter
+    default: return launch_v3<E, 256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
+  }
+}
+
 // Split-K plan of a weight-gradient GEMM on the ring kernel (shared by the dispatcher and pm_gemm_workspace_bytes).
 // 256x256 tiles (twice the MFMAs per barrier) from 2x2 tiles up: ViT-B qkv / fc1 / fc2 gradients 74 us vs 83 with
 // 256x128; the MAE decoder's 512-wide gradients (K = 50 432 tokens) +2.8 % step rate; neutral for 768x768.
@@ -1392,8 +1429,9 @@ inline WgradPlan plan_wgrad(int M, int N, int K, int force_cfg, int wgrad_blocks
   p.split = split;
   return p;
 }
+inline bool is16(int dtype) { return dtype == PM_BF16 || dtype == PM_F16; }
 inline bool wgrad_ring_shape(int in_dtype, int a_kmajor, int b_kmajor, int M, int N, int K) {
-  return in_dtype == PM_BF16 && a_kmajor && b_kmajor && (K % V3_KE) == 0 && K >= 2048 && M >= 256 && N >= 128;
+  return is16(in_dtype) && a_kmajor && b_kmajor && (K % V3_KE) == 0 && K >= 2048 && M >= 256 && N >= 128;
 }
 
 int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb, int b_kmajor, int in_dtype,
@@ -1413,7 +1451,7 @@ extern "C" size_t pm_gemm_workspace_bytes(int a_kmajor, int b_kmajor, int in_dty
     return p.split > 1 ? (size_t)p.split * M * N * sizeof(float) : 0;
   }
   // 128x128 split-K path: up to 16 slabs
-  const int ke = in_dtype == PM_BF16 ? 64 : 32;
+  const int ke = is16(in_dtype) ? 64 : 32;
   if (K % ke) return 0;
   const int nk = K / ke, tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   if (tiles >= 256 || nk < 16) return 0;
@@ -1476,9 +1514,10 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
   if (wgrad_blocks > 1024) wgrad_blocks = 1024;
   if (!A || !B || !C) return PM_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return PM_ESHAPE;
-  if (in_dtype != PM_BF16 && in_dtype != PM_F32) return PM_EINVAL;
-  if (c_dtype != PM_BF16 && c_dtype != PM_F32) return PM_EINVAL;
-  const int epc = in_dtype == PM_BF16 ? 8 : 4;
+  if (!is16(in_dtype) && in_dtype != PM_F32) return PM_EINVAL;
+  if (!is16(c_dtype) && c_dtype != PM_F32) return PM_EINVAL;
+  if (is16(in_dtype) && is16(c_dtype) && c_dtype != in_dtype) return PM_EINVAL;  // a 16-bit C has the operands' type
+  const int epc = is16(in_dtype) ? 8 : 4;
   // 16-byte global chunks: the contiguous dimension of each operand and its leading dimension must be chunk multiples
   if ((lda % epc) || (ldb % epc)) return PM_EALIGN;
   if (!a_kmajor && (K % epc)) return PM_EALIGN;
@@ -1504,14 +1543,15 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
   a.stamps = g_stamps;
 #endif
   hipStream_t s = pm_stream(stream);
-  const int ke = in_dtype == PM_BF16 ? 64 : 32;
+  const int ke = is16(in_dtype) ? 64 : 32;
   const bool fast = (K % ke) == 0;
   if (!fast) {
     a.ksteps_split = 0;
-    return in_dtype == PM_BF16 ? launch_generic<__bf16>(a, a_kmajor, b_kmajor, s) : launch_generic<float>(a, a_kmajor, b_kmajor, s);
+    PM_DISPATCH_ACT(in_dtype, T, return launch_generic<T>(a, a_kmajor, b_kmajor, s));
+    return PM_EINVAL;
   }
   // large-tile ring kernel: bf16, X k-normal (forward and dgrad GEMMs), big M
-  if (in_dtype == PM_BF16 && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (force_cfg & 63) != 1) {
+  if (is16(in_dtype) && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (force_cfg & 63) != 1) {
     // Tile / pipeline choice, tuned on the ViT-B/16 shapes at M = 12608 (scratch/bench_gemm6.py).
     // pm_debug_gemm_config(cfg) forces one of the variants below (0 = the heuristics).
     int cfg = force_cfg & 63;
@@ -1548,26 +1588,7 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
       const int cls = !b_kmajor ? (epilogue == PM_EPI_GELU ? 1 : epilogue == PM_EPI_RESIDUAL ? 2 : 0) : (epilogue == PM_EPI_DGELU ? 4 : 3);
       if (cfg_class_override()[cls]) cfg = cfg_class_override()[cls];
     }
-    switch (cfg) {
-      case 6: return launch_v3<256, 256, 2, 4, 4, 2, true>(a, b_kmajor, s);          // plain ring loop, register epilogue
-      case 8: return launch_v3<256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);   // ping-pong, LDS-staged epilogue
-      case 40: if (!b_kmajor) return launch_v3_m16(a, s);                            // the same on v_mfma_f32_16x16x32_bf16
-               return launch_v3<256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);
-      case 9: return launch_v3<256, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);    // ping-pong, register epilogue
-      case 10: return launch_v3<192, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);   // 192-row tiles: finer M granularity
-      // software-pipelined loop (fragment reads and DMA issue between the wave's own MFMAs)
-      case 24: return launch_v3<256, 256, 2, 4, 4, 2, false, false, 8, true>(a, b_kmajor, s);
-      case 25: return launch_v3<256, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);
-      case 26: return launch_v3<192, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);
-      // Measured and no longer instantiated (the template still admits them):
-      //   two 4-wave blocks per CU   launch_v3<128, 256, 2, 2, 3, 2, false, false, 4, true>   slower on every shape
-      //   two 8-wave blocks per CU   launch_v3<256, 128, 4, 2, 3, 4, true> / <128, 256, 2, 4, 3, 4, true>: <= 128 VGPRs, 100-150
-      //                              spills, 85 instead of 128 FLOP per LDS-fill byte: 1.7x slower
-      //   one wave per SIMD          launch_v3<256, 256, 2, 2, 4, 1, true, false, 4, true>: 128x128 per wave, 512 VGPRs, 2/3 of the
-      //                              LDS reads per FLOP: equals the 8-wave loop on long-K dgrads (decoder dfc1 1.0 PFLOP/s both),
-      //                              loses 5-30 % wherever prologue / epilogue matter
-      default: return launch_v3<256, 256, 2, 4, 4, 2, false>(a, b_kmajor, s);
-    }
+    PM_DISPATCH_16(in_dtype, E, return launch_v3_cfg<E>(cfg, a, b_kmajor, s));
   }
   const int nk = K / ke;
   a.ksteps_split = nk;
@@ -1590,9 +1611,10 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
       w.C = workspace;
       w.epilogue = PM_EPI_STORE;
     }
-    const int st = wv == 1   ? launch_v3_wgrad<256, 128, 4, 2, false>(w, s)
-                   : wv == 2 ? launch_v3_wgrad<256, 256, 2, 4, false>(w, s)
-                             : launch_v3_wgrad<256, 256, 2, 4, true>(w, s);
+    int st = PM_EINVAL;
+    PM_DISPATCH_16(in_dtype, E, st = wv == 1   ? launch_v3_wgrad<E, 256, 128, 4, 2, false>(w, s)
+                                     : wv == 2 ? launch_v3_wgrad<E, 256, 256, 2, 4, false>(w, s)
+                                               : launch_v3_wgrad<E, 256, 256, 2, 4, true>(w, s));
     if (st || w.split_k == 1) return st;
     const long nvec = (long)M * (N >> 2);
     int grid = (int)((nvec + 255) / 256);
@@ -1612,7 +1634,8 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
       a.split_k = (nk + a.ksteps_split - 1) / a.ksteps_split;  // no empty split
       void* out = a.C;
       a.C = workspace;
-      int st = in_dtype == PM_BF16 ? launch_glds<__bf16>(a, a_kmajor, b_kmajor, s) : launch_glds<float>(a, a_kmajor, b_kmajor, s);
+      int st = PM_EINVAL;
+      PM_DISPATCH_ACT(in_dtype, T, st = launch_glds<T>(a, a_kmajor, b_kmajor, s));
       if (st) return st;
       const long nvec = (long)M * (N >> 2);
       int grid = (int)((nvec + 255) / 256);
@@ -1622,7 +1645,8 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
       return pm_check_launch();
     }
   }
-  return in_dtype == PM_BF16 ? launch_glds<__bf16>(a, a_kmajor, b_kmajor, s) : launch_glds<float>(a, a_kmajor, b_kmajor, s);
+  PM_DISPATCH_ACT(in_dtype, T, return launch_glds<T>(a, a_kmajor, b_kmajor, s));
+  return PM_EINVAL;
 }
 
 }  // namespace
@@ -1678,7 +1702,7 @@ GroupPlan plan_group(const pm_wgrad_item* items, int n, int K, int in_dtype) {
   GroupPlan pl{PM_OK, 256, 1, 0, 0};
   if (!items || n <= 0) { pl.status = PM_EINVAL; return pl; }
   if (n > kMaxGroup || K <= 0) { pl.status = PM_ESHAPE; return pl; }
-  if (in_dtype != PM_BF16) { pl.status = PM_ESHAPE; return pl; }           // (f32 mode keeps the per-GEMM split-K path)
+  if (!is16(in_dtype)) { pl.status = PM_ESHAPE; return pl; }               // (f32 mode keeps the per-GEMM split-K path)
   if ((K % V3_KE) != 0 || K < 2048) { pl.status = PM_ESHAPE; return pl; }  // ring kernel: whole 32-element k-steps, long reduction
   long t256 = 0;
   for (int i = 0; i < n; ++i) {
@@ -1750,6 +1774,9 @@ extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_d
   WgradGroupArgs g;
   g.n = n; g.K = K; g.split = pl.split; g.ksteps_split = pl.ksteps_split;
   g.auto_order = group_order_auto();
+#ifdef PM_GEMM_STAMP
+  g.stamps = g_stamps ? g_stamps + 4096L * 8 * 16 : nullptr;  // rows [4096, 4608) x 8 waves of the caller's stamp buffer
+#endif
   int total = 0;
   long vec = 0;
   char* ws = reinterpret_cast<char*>(workspace);
@@ -1787,17 +1814,19 @@ extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_d
     if (grid > work) grid = work;
   }
   hipStream_t s = pm_stream(stream);
-  if (bn == 256) {
-    auto kern = wgrad_group_kernel<256, 256, 2, 4>;
-    constexpr int ring = 4 * (256 + 256) * 64;
-    PM_ALLOW_LDS(kern, ring);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ring, s, g);
-  } else {
-    auto kern = wgrad_group_kernel<256, 128, 4, 2>;
-    constexpr int ring = 4 * (256 + 128) * 64;
-    PM_ALLOW_LDS(kern, ring);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ring, s, g);
-  }
+  PM_DISPATCH_16(in_dtype, E, {
+    if (bn == 256) {
+      auto kern = wgrad_group_kernel<256, 256, 2, 4, E>;
+      constexpr int ring = 4 * (256 + 256) * 64;
+      PM_ALLOW_LDS(kern, ring);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ring, s, g);
+    } else {
+      auto kern = wgrad_group_kernel<256, 128, 4, 2, E>;
+      constexpr int ring = 4 * (256 + 128) * 64;
+      PM_ALLOW_LDS(kern, ring);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ring, s, g);
+    }
+  });
   int st = pm_check_launch();
   if (st || pl.split == 1) return st;
   const long items_r = g.bias_begin + g.bias_total;
