@@ -390,6 +390,11 @@ int pm_supervised_loss_fwd(const float* logits, const long long* targets, const 
 /* out[i] = x[i] * scale[0] (scale: f32 device scalar) -- chains an upstream d loss into the saved dlogits. */
 int pm_scale(const float* x, const float* scale, float* out, long n, void* stream);
 
+/* out[i] = dy[i] * gelu_erf'(pre[i]) over n elements of `dtype` (n % 4 == 0): the backward of timm Mlp's nn.GELU
+ * (models_mae.py:39-41 through timm Block) as a stand-alone pass, for callers that compose blocks from the per-kernel ops
+ * (the training step gets the same product from the dfc2 GEMM's PM_EPI_DGELU epilogue).  out may alias dy. */
+int pm_dgelu(const void* dy, const void* pre, void* out, int dtype, long n, void* stream);
+
 /* Fused multi-tensor AdamW over one flat f32 parameter range (torch.optim.AdamW semantics,
  * tc.py:5766-5768 / main_pretrain.py:218) that also refreshes the act-typed shadow copy used by the GEMMs.
  * grad_scale multiplies the gradient (1/world, 1/accum).  step >= 1. */
@@ -397,12 +402,23 @@ int pm_adamw(float* p, const float* g, float* m, float* v, void* shadow, int sha
              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
 /* hipGraph-replayable form of the same update: the hyper-parameters live in DEVICE memory, one 16-float record per
- * param group: [0] lr [1] beta1 [2] beta2 [3] eps [4] weight_decay [5] grad_scale [6] step [7] bc1 [8] 1/sqrt(bc2).
+ * param group: [0] lr [1] beta1 [2] beta2 [3] eps [4] weight_decay [5] grad_scale [6] step [7] bc1 [8] 1/sqrt(bc2)
+ * [9] skip flag [10] 1 / loss scale (both written by pm_loss_scale_update; 0 = no loss scaling).
  * pm_adamw_tick advances step and the bias corrections of `n_groups` records; pm_adamw_dev applies one record to a
- * flat range.  A captured step therefore replays correctly while the host changes lr between replays. */
+ * flat range (gradient x [5] x [10]); both return without touching anything while [9] is set.  A captured step therefore
+ * replays correctly while the host changes lr between replays. */
 int pm_adamw_tick(float* hyper, int n_groups, void* stream);
 int pm_adamw_dev(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long n,
                  const float* hyper, void* stream);
+
+/* Dynamic loss scaling of precision mode fp16, on the device: GradScaler.step() + update() of the reference's AMP loop
+ * (train_classification.py:4533-4546; engine_pretrain.py:65-72 via mae/util/misc.py:252-282) without the host read-back.
+ * state: f32[8] = [0] scale [1] growth tracker [2] found_inf of the last step [3] skipped steps [4] steps [5] 1/scale used.
+ * stats: the pm_grad_stats triple of THIS step's (scaled) gradients.  Writes the skip flag and 1/scale into the `n_groups`
+ * AdamW records, then moves the scale: x backoff_factor after a non-finite step, x growth_factor after growth_interval
+ * clean steps in a row.  Launch order on one stream: pm_grad_stats ..., pm_loss_scale_update, pm_adamw_tick, pm_adamw_dev ... */
+int pm_loss_scale_update(float* state, const float* stats, float* hyper, int n_groups, float growth_factor,
+                         float backoff_factor, int growth_interval, void* stream);
 
 /* One-pass gradient statistics over a flat f32 range: out[0] += sum(g^2), out[1] += #NaN, out[2] += #Inf
  * (the device-side counterpart of tc.py:1437-1454 _compute_grad_norm and misc.py:387-400 detect_grad_anomalies). */

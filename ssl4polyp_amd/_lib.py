@@ -9,7 +9,7 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
 
-PM_F32, PM_BF16 = 0, 1
+PM_F32, PM_BF16, PM_F16 = 0, 1, 2
 EPI_STORE, EPI_GELU, EPI_RESIDUAL, EPI_DGELU, EPI_ACCUM = 0, 1, 2, 3, 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -65,9 +65,11 @@ SIGNATURES = {
     "pm_adamw_tick": [P, I, P],
     "pm_adamw_dev": [P, P, P, P, P, I, L, P, P],
     "pm_grad_stats": [P, L, P, P],
+    "pm_loss_scale_update": [P, P, P, I, F, F, I, P],
+    "pm_dgelu": [P, P, P, I, L, P],
 }
 
-ABI_VERSION = 9  # pm_abi_version() of the library these signatures describe
+ABI_VERSION = 10  # pm_abi_version() of the library these signatures describe
 PM_GROUP_WHOLE_K = -1  # pm_wgrad_group(max_blocks=...): never slice, whole-K 256x256 tiles
 
 WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4
@@ -160,4 +162,6 @@ def dtype_code(torch_dtype) -> int:
         return PM_F32
     if torch_dtype == torch.bfloat16:
         return PM_BF16
+    if torch_dtype == torch.float16:
+        return PM_F16
     raise PolypMaeError(f"unsupported dtype {torch_dtype}")

@@ -99,8 +99,8 @@ __device__ __forceinline__ f32x16 mma_imgT_acc(const char* PM_LDS_IMAGE img, int
       a.u[3] = ((unsigned)(unsigned short)hi[2]) | (((unsigned)(unsigned short)hi[3]) << 16);
       // element j of lane half hh  <->  row 16s + 8(j>>2) + 4hh + (j&3) of X  ==  registers 8s..8s+7 in order
 #pragma unroll
-      for (int j = 0; j < 8; ++j) b.h[j] = (__bf16)x[8 * s + j];
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+      for (int j = 0; j < 8; ++j) frag_set<T>(b, j, x[8 * s + j]);
+      acc = mfma16B<T>(a, b, acc);
     }
   } else {
     const int hh = lane >> 5;
@@ -257,10 +257,7 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const
       fdo[kk] = frag_global<T>(dorow, qv, kk, lane);
       const Frag16 fo = frag_global<T>(orow, qv, kk, lane);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        if constexpr (sizeof(T) == 2) dl += (float)fdo[kk].h[e] * (float)fo.h[e];
-        else dl += fdo[kk].f[e] * fo.f[e];
-      }
+      for (int e = 0; e < EPC; ++e) dl += frag_get<T>(fdo[kk], e) * frag_get<T>(fo, e);
     }
     dl += __shfl_xor(dl, 32, 64);
     const long sidx = ((long)b * H + h) * N + q;
@@ -387,8 +384,9 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(cons
 // double buffer while the current head computes, so only the first head of a workgroup sees its load latency.
 // One wave per 32-query tile holds the whole score row block in registers (7 x 16 accumulators): no online rescaling,
 // one max / one sum per row; S^T = K Q^T for all key tiles first (28 MFMAs back to back), then exp and P V per key tile.
-template <int RB> __device__ __forceinline__ void dma_rows(char* img, const __bf16* __restrict__ base, long ld, int rows_valid,
-                                                            int piece, int lane) {
+template <int RB, typename T> __device__ __forceinline__ void dma_rows(char* img, const T* __restrict__ base, long ld, int rows_valid,
+                                                                        int piece, int lane) {
+  static_assert(sizeof(T) == 2, "16-bit rows");
   // piece = one wave instruction = 1 KiB of the image = 1024 / RB rows; lane -> (row, slot); source chunk = slot ^ swz(row)
   constexpr int CPR = RB / 16, RPP = 1024 / RB;
   const int row = piece * RPP + lane / CPR, cs = lane % CPR;
@@ -398,10 +396,9 @@ template <int RB> __device__ __forceinline__ void dma_rows(char* img, const __bf
                                    (__attribute__((address_space(3))) void*)(img + 1024 * piece), 16, 0, 0);
 }
 
-template <int DH, int NT>
-__global__ __launch_bounds__(NT * 64) void attn_fwd2_kernel(const __bf16* __restrict__ qkv, __bf16* __restrict__ out,
+template <typename T, int DH, int NT>
+__global__ __launch_bounds__(NT * 64) void attn_fwd2_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                            float* __restrict__ lse, int N, int H, int BH, float scale) {
-  using T = __bf16;
   constexpr int RB = DH * 2;
   constexpr int IMG = NT * 32 * RB;  // bytes per image
   constexpr int PCS = IMG / 1024;    // DMA pieces per image
@@ -491,7 +488,7 @@ __global__ __launch_bounds__(NT * 64) void attn_fwd2_kernel(const __bf16* __rest
   }
 }
 
-template <int DH>
+template <typename T, int DH>
 int launch_fwd2(const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t s) {
   constexpr int NT = 7;
   const int BH = B * H;
@@ -500,9 +497,9 @@ int launch_fwd2(const void* qkv, void* out, float* lse, int B, int N, int H, hip
   const int grid = (BH + rounds - 1) / rounds;  // ... spread evenly: no workgroup walks one head more than another
   constexpr size_t lds = 5 * NT * 32 * DH * 2;
   const float scale = 1.0f / sqrtf((float)DH);
-  auto kern = attn_fwd2_kernel<DH, NT>;
+  auto kern = attn_fwd2_kernel<T, DH, NT>;
   PM_ALLOW_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, s, (const __bf16*)qkv, (__bf16*)out, lse, N, H, BH, scale);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, s, (const T*)qkv, (T*)out, lse, N, H, BH, scale);
   return pm_check_launch();
 }
 
@@ -529,10 +526,10 @@ int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, hipS
 //   pass 2 (wave = key tile):   S, dP -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS
 // S and dP are still recomputed in pass 2 (no cross-wave reduction, no atomics: deterministic); what disappears is the
 // second trip of qkv / dO through HBM, the per-lane global fragment loads and the delta round trip.
-template <int DH, int NT>
-__global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* __restrict__ qkv, const __bf16* __restrict__ out,
-                                                                const __bf16* __restrict__ dout,
-                                                                const float* __restrict__ lse, __bf16* __restrict__ dqkv,
+template <typename T, int DH, int NT>
+__global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
+                                                                const T* __restrict__ dout,
+                                                                const float* __restrict__ lse, T* __restrict__ dqkv,
                                                                 int N, int H, float scale
 #ifdef PM_ATTN_DEBUG
                                                                 , int dbg  // diagnostic build: bit 0 skips pass 1, bit 1 pass 2
@@ -541,7 +538,6 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* _
 #ifndef PM_ATTN_DEBUG
   constexpr int dbg = 0;
 #endif
-  using T = __bf16;
   constexpr int RB = DH * 2;
   constexpr int IMG = NT * 32 * RB;
   constexpr int PCS = IMG / 1024;
@@ -607,7 +603,7 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* _
     fq[kk] = frag_rows<T, DH>(imgQ, wave * 32, kk, lane);
     fdo[kk] = frag_rows<T, DH>(imgDO, wave * 32, kk, lane);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dl += (float)fdo[kk].h[e] * (float)fo[kk].h[e];
+    for (int e = 0; e < 8; ++e) dl += frag_get<T>(fdo[kk], e) * frag_get<T>(fo[kk], e);
   }
   dl += __shfl_xor(dl, 32, 64);
   if (!qv) dl = 0.f;
@@ -688,30 +684,30 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const __bf16* _
   }
 }
 
-template <int DH, int NT>
+template <typename T, int DH, int NT>
 int launch_bwd_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N, int H,
                      hipStream_t s) {
   const size_t lds = 4 * NT * 32 * DH * 2 + 2 * NT * 32 * sizeof(float);
   const float scale = 1.0f / sqrtf((float)DH);
-  auto kern = attn_bwd_fused_kernel<DH, NT>;
+  auto kern = attn_bwd_fused_kernel<T, DH, NT>;
   PM_ALLOW_LDS(kern, lds);
 #ifdef PM_ATTN_DEBUG
   static const int dbg = [] { const char* e = getenv("PM_ATTN_BWD_SKIP"); return e ? atoi(e) : 0; }();
-  hipLaunchKernelGGL(kern, dim3(B * H), dim3(NT * 64), lds, s, (const __bf16*)qkv, (const __bf16*)out, (const __bf16*)dout, lse,
-                     (__bf16*)dqkv, N, H, scale, dbg);
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(NT * 64), lds, s, (const T*)qkv, (const T*)out, (const T*)dout, lse,
+                     (T*)dqkv, N, H, scale, dbg);
 #else
-  hipLaunchKernelGGL(kern, dim3(B * H), dim3(NT * 64), lds, s, (const __bf16*)qkv, (const __bf16*)out, (const __bf16*)dout, lse,
-                     (__bf16*)dqkv, N, H, scale);
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(NT * 64), lds, s, (const T*)qkv, (const T*)out, (const T*)dout, lse,
+                     (T*)dqkv, N, H, scale);
 #endif
   return pm_check_launch();
 }
 
-template <int DH>
+template <typename T, int DH>
 int dispatch_bwd_fused(int nt, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N,
                        int H, hipStream_t s) {
-  if (nt <= 1) return launch_bwd_fused<DH, 1>(qkv, out, dout, lse, dqkv, B, N, H, s);
-  if (nt <= 2) return launch_bwd_fused<DH, 2>(qkv, out, dout, lse, dqkv, B, N, H, s);
-  return launch_bwd_fused<DH, 7>(qkv, out, dout, lse, dqkv, B, N, H, s);
+  if (nt <= 1) return launch_bwd_fused<T, DH, 1>(qkv, out, dout, lse, dqkv, B, N, H, s);
+  if (nt <= 2) return launch_bwd_fused<T, DH, 2>(qkv, out, dout, lse, dqkv, B, N, H, s);
+  return launch_bwd_fused<T, DH, 7>(qkv, out, dout, lse, dqkv, B, N, H, s);
 }
 
 template <typename T, int DH, int NT>
@@ -760,7 +756,7 @@ inline int check_shape(int B, int N, int H, int dh, int dtype) {
   if (B <= 0 || N <= 0 || H <= 0) return PM_ESHAPE;
   if (N > 224) return PM_ESHAPE;
   if (dh != 32 && dh != 64) return PM_ESHAPE;
-  if (dtype != PM_BF16 && dtype != PM_F32) return PM_EINVAL;
+  if (dtype != PM_BF16 && dtype != PM_F16 && dtype != PM_F32) return PM_EINVAL;
   return PM_OK;
 }
 
@@ -773,13 +769,14 @@ extern "C" int pm_attention_fwd(const void* qkv, void* out, float* lse, int B, i
   if (st) return st;
   const int nt = (N + 31) / 32;
   hipStream_t s = pm_stream(stream);
-  if (dtype == PM_BF16) {
+  if (dtype != PM_F32) {
     // persistent double-buffered form for the ViT-B encoder heads (dh = 64, N = 197: 26 vs 28 us); the 32-wide MAE decoder
     // heads are faster one block per head, two blocks per CU (70 vs 77 us) -- both are bound by the strided qkv reads
-    if (nt == 7 && dh == 64 && !attn_v1()) return launch_fwd2<64>(qkv, out, lse, B, N, H, s);
-    if (nt == 7 && dh == 32 && attn_fwd2_dh32()) return launch_fwd2<32>(qkv, out, lse, B, N, H, s);
-    return dh == 64 ? dispatch_fwd<__bf16, 64>(nt, qkv, out, lse, B, N, H, s)
-                    : dispatch_fwd<__bf16, 32>(nt, qkv, out, lse, B, N, H, s);
+    PM_DISPATCH_16(dtype, T, {
+      if (nt == 7 && dh == 64 && !attn_v1()) return launch_fwd2<T, 64>(qkv, out, lse, B, N, H, s);
+      if (nt == 7 && dh == 32 && attn_fwd2_dh32()) return launch_fwd2<T, 32>(qkv, out, lse, B, N, H, s);
+      return dh == 64 ? dispatch_fwd<T, 64>(nt, qkv, out, lse, B, N, H, s) : dispatch_fwd<T, 32>(nt, qkv, out, lse, B, N, H, s);
+    });
   }
   return dh == 64 ? dispatch_fwd<float, 64>(nt, qkv, out, lse, B, N, H, s)
                   : dispatch_fwd<float, 32>(nt, qkv, out, lse, B, N, H, s);
@@ -792,12 +789,14 @@ extern "C" int pm_attention_bwd(const void* qkv, const void* out, const void* do
   if (st) return st;
   const int nt = (N + 31) / 32;
   hipStream_t s = pm_stream(stream);
-  if (dtype == PM_BF16) {
-    if (!attn_v1())
-      return dh == 64 ? dispatch_bwd_fused<64>(nt, qkv, out, dout, lse, dqkv, B, N, H, s)
-                      : dispatch_bwd_fused<32>(nt, qkv, out, dout, lse, dqkv, B, N, H, s);
-    return dh == 64 ? dispatch_bwd<__bf16, 64>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
-                    : dispatch_bwd<__bf16, 32>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+  if (dtype != PM_F32) {
+    PM_DISPATCH_16(dtype, T, {
+      if (!attn_v1())
+        return dh == 64 ? dispatch_bwd_fused<T, 64>(nt, qkv, out, dout, lse, dqkv, B, N, H, s)
+                        : dispatch_bwd_fused<T, 32>(nt, qkv, out, dout, lse, dqkv, B, N, H, s);
+      return dh == 64 ? dispatch_bwd<T, 64>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
+                      : dispatch_bwd<T, 32>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+    });
   }
   return dh == 64 ? dispatch_bwd<float, 64>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
                   : dispatch_bwd<float, 32>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s);

@@ -11,7 +11,7 @@ extern "C" int pm_vit_block_fwd(const pm_block_fwd_desc* d, void* stream) {
   if (!d->x || !d->x_mid || !d->x_out || !d->ln1 || !d->qkv || !d->attn || !d->ln2 || !d->h_pre || !d->h_act) return PM_EINVAL;
   if (d->rows <= 0 || d->samples <= 0 || d->N <= 0 || d->rows != d->samples * d->N) return PM_ESHAPE;
   if (d->D <= 0 || d->Hd <= 0 || d->heads <= 0 || (d->D % d->heads)) return PM_ESHAPE;
-  if (d->dtype != PM_BF16 && d->dtype != PM_F32) return PM_EINVAL;
+  if (d->dtype != PM_BF16 && d->dtype != PM_F16 && d->dtype != PM_F32) return PM_EINVAL;
   const int M = d->rows, D = d->D, Hd = d->Hd, dt = d->dtype;
   pm_gemm_opts opts;
   opts.max_blocks = 0;
@@ -46,7 +46,7 @@ extern "C" int pm_vit_block_bwd(const pm_block_bwd_desc* d, void* stream) {
     return PM_EINVAL;
   if (!d->g_qkv_w || !d->g_proj_w || !d->g_fc1_w || !d->g_fc2_w || !d->side_stream || !d->ev_fork || !d->ev_done) return PM_EINVAL;
   if (d->samples <= 0 || d->N <= 0 || d->D <= 0 || d->Hd <= 0 || d->heads <= 0 || (d->D % d->heads)) return PM_ESHAPE;
-  if (d->dtype != PM_BF16 && d->dtype != PM_F32) return PM_EINVAL;
+  if (d->dtype != PM_BF16 && d->dtype != PM_F16 && d->dtype != PM_F32) return PM_EINVAL;
   const int M = d->samples * d->N, D = d->D, Hd = d->Hd, dt = d->dtype;
   hipStream_t main = pm_stream(stream), side = pm_stream(d->side_stream);
   pm_gemm_opts opts;
@@ -56,6 +56,7 @@ extern "C" int pm_vit_block_bwd(const pm_block_bwd_desc* d, void* stream) {
   // the grouped weight gradients are the only launch of this block that can refuse its shapes: plan them BEFORE anything is
   // enqueued, so that a refusal leaves both streams untouched (the caller then issues the block kernel by kernel)
   pm_wgrad_item it[4];
+  size_t ws_need = 0;  // slab scratch of the one-launch k-sliced group (0: whole-K tiles)
   {
     const void* dys[4] = {d->dx_act, d->d_hidden, d->dmid_act, d->d_qkv};
     const void* xs[4] = {d->h_act, d->ln2, d->attn, d->ln1};
@@ -67,7 +68,7 @@ extern "C" int pm_vit_block_bwd(const pm_block_bwd_desc* d, void* stream) {
       it[j].dY = dys[j]; it[j].lddy = n_out[j]; it[j].X = xs[j]; it[j].ldx = n_in[j]; it[j].dW = dws[j]; it[j].lddw = n_in[j];
       it[j].n_out = n_out[j]; it[j].n_in = n_in[j]; it[j].accumulate = (d->accumulate >> acc_bit[j]) & 1; it[j].dbias = dbs[j];
     }
-    if ((st = pm_wgrad_group_plan(it, 4, M, dt, nullptr, nullptr, nullptr))) return st;
+    if ((st = pm_wgrad_group_plan(it, 4, M, dt, &ws_need, nullptr, nullptr))) return st;
   }
   // two launches (fc2, fc1 | proj, qkv) only when the MLP pair alone is a whole-K group; the small pair then runs whole-K too
   bool two = false;
@@ -78,6 +79,9 @@ extern "C" int pm_vit_block_bwd(const pm_block_bwd_desc* d, void* stream) {
     if ((st = pm_wgrad_group_plan(it + 2, 2, M, dt, nullptr, nullptr, nullptr))) return st;
     two = slices == 1;
   }
+  // a k-sliced group without room for its slabs would silently run as whole-K 256x128 tiles (pm_wgrad_group's fallback): a
+  // different launch geometry than the caller planned for -- refuse instead, before anything is enqueued
+  if (!two && ws_need > 0 && (!d->ws_group || d->ws_group_bytes < ws_need)) return PM_EINVAL;
   hipStream_t side2 = two ? pm_stream(d->side_stream2) : nullptr;
   if (d->ev_join && hipStreamWaitEvent(main, (hipEvent_t)d->ev_join, 0) != hipSuccess) return PM_ELAUNCH;
   // ---- MLP branch

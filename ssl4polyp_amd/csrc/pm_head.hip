@@ -483,14 +483,11 @@ extern "C" int pm_vit_head_bwd(const float* dlogits, const float* dfeat, const f
   if (pool == 1 && N < 2) return PM_ESHAPE;
   hipStream_t s = pm_stream(stream);
   if (dx) {  // NULL: frozen backbone, nothing below the head needs a gradient
-    if (act_dtype != PM_BF16 && act_dtype != PM_F32) return PM_EINVAL;
 #define PM_HEAD_BWD(KERN, T)                                                                                            \
   hipLaunchKernelGGL(KERN<T>, dim3(B), dim3(256), 0, s, dlogits, dfeat, x, N, gamma, W, mean, rstd, dx, (T*)dx_act, D, n_class)
-    if (pool == 0) {
-      if (act_dtype == PM_BF16) PM_HEAD_BWD(cls_head_bwd_kernel, __bf16); else PM_HEAD_BWD(cls_head_bwd_kernel, float);
-    } else {
-      if (act_dtype == PM_BF16) PM_HEAD_BWD(spatial_head_bwd_kernel, __bf16); else PM_HEAD_BWD(spatial_head_bwd_kernel, float);
-    }
+    PM_DISPATCH_ACT(act_dtype, T, {
+      if (pool == 0) PM_HEAD_BWD(cls_head_bwd_kernel, T); else PM_HEAD_BWD(spatial_head_bwd_kernel, T);
+    });
 #undef PM_HEAD_BWD
   }
   if (dW || dbias || dgamma || dbeta)

@@ -231,14 +231,8 @@ extern "C" int pm_layernorm_fwd(const float* x, long ldx, const float* gamma, co
   if (!x || !gamma || !beta || !y || !mean || !rstd) return PM_EINVAL;
   if (M <= 0 || D <= 0 || D > 1024 || (D & 3) || (ldx & 3)) return PM_ESHAPE;
   const int grid = (M + 3) / 4 > 4096 ? 4096 : (M + 3) / 4;
-  if (out_dtype == PM_BF16)
-    hipLaunchKernelGGL(ln_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, pm_stream(stream), x, ldx, gamma, beta,
-                       (__bf16*)y, mean, rstd, M, D, eps);
-  else if (out_dtype == PM_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, pm_stream(stream), x, ldx, gamma, beta,
-                       (float*)y, mean, rstd, M, D, eps);
-  else
-    return PM_EINVAL;
+  PM_DISPATCH_ACT(out_dtype, T, hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(grid), dim3(256), 0, pm_stream(stream), x, ldx, gamma,
+                                                   beta, (T*)y, mean, rstd, M, D, eps));
   return pm_check_launch();
 }
 
@@ -266,13 +260,9 @@ extern "C" int pm_layernorm_bwd(const void* dy, int dy_dtype, const float* x, lo
 #define PM_LN_BWD(TD, NV)                                                                                               \
   hipLaunchKernelGGL((ln_bwd_kernel<TD, TD, NV>), dim3(grid), dim3(256), 0, s, (const TD*)dy, x, ldx, gamma, mean, rstd, \
                      dres, lddres, dx, lddx, (TD*)dx_act, dgamma, dbeta, dcolsum, partials, M, D)
-  if (dy_dtype == PM_BF16) {
-    if (nv == 1) PM_LN_BWD(__bf16, 1); else if (nv == 2) PM_LN_BWD(__bf16, 2); else if (nv == 3) PM_LN_BWD(__bf16, 3); else PM_LN_BWD(__bf16, 4);
-  } else if (dy_dtype == PM_F32) {
-    if (nv == 1) PM_LN_BWD(float, 1); else if (nv == 2) PM_LN_BWD(float, 2); else if (nv == 3) PM_LN_BWD(float, 3); else PM_LN_BWD(float, 4);
-  } else {
-    return PM_EINVAL;
-  }
+  PM_DISPATCH_ACT(dy_dtype, T, {
+    if (nv == 1) PM_LN_BWD(T, 1); else if (nv == 2) PM_LN_BWD(T, 2); else if (nv == 3) PM_LN_BWD(T, 3); else PM_LN_BWD(T, 4);
+  });
 #undef PM_LN_BWD
   if (partials)
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((D + 63) / 64, 3), dim3(1024), 0, s, partials, dgamma, dbeta, dcolsum, grid, D);

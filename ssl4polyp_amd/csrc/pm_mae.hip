@@ -336,12 +336,8 @@ extern "C" int pm_mae_unshuffle_bwd(const float* dout, const int* ids_shuffle, v
   if (!dout || !ids_shuffle || !demb) return PM_EINVAL;
   if (B <= 0 || L <= 0 || keep <= 0 || keep > L || D <= 0 || (D & 3)) return PM_ESHAPE;
   const dim3 grid(cap_grid((long)B * (keep + 1), 4, 4096));
-  if (act_dtype == PM_BF16)
-    hipLaunchKernelGGL(unshuffle_bwd_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), dout, ids_shuffle, (__bf16*)demb, B, L, keep, D);
-  else if (act_dtype == PM_F32)
-    hipLaunchKernelGGL(unshuffle_bwd_kernel<float>, grid, dim3(256), 0, pm_stream(stream), dout, ids_shuffle, (float*)demb, B, L, keep, D);
-  else
-    return PM_EINVAL;
+  PM_DISPATCH_ACT(act_dtype, T, hipLaunchKernelGGL(unshuffle_bwd_kernel<T>, grid, dim3(256), 0, pm_stream(stream), dout, ids_shuffle,
+                                                   (T*)demb, B, L, keep, D));
   if (dmask_token && keep < L) {
     // one block row per 64 masked positions, up to 1024 rows: each wave then walks ~16 (index, row) load pairs instead of 73
     // (70 -> ~20 us at B = 256, in the serial stretch between the decoder's and the encoder's backward)
@@ -382,13 +378,7 @@ extern "C" int pm_mae_loss_bwd(const float* imgs, const float* pred, long ldp, i
   const int L = (img / p) * (img / p);
   const int hc = has_cls_row ? 1 : 0;
   const dim3 grid(cap_grid((long)B * (L + hc), 4, 8192));
-  if (act_dtype == PM_BF16)
-    hipLaunchKernelGGL(loss_bwd_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), imgs, pred, ldp, hc, mask, sums, dloss,
-                       (__bf16*)dpred, B, L, C, img, p, norm_pix);
-  else if (act_dtype == PM_F32)
-    hipLaunchKernelGGL(loss_bwd_kernel<float>, grid, dim3(256), 0, pm_stream(stream), imgs, pred, ldp, hc, mask, sums, dloss,
-                       (float*)dpred, B, L, C, img, p, norm_pix);
-  else
-    return PM_EINVAL;
+  PM_DISPATCH_ACT(act_dtype, T, hipLaunchKernelGGL(loss_bwd_kernel<T>, grid, dim3(256), 0, pm_stream(stream), imgs, pred, ldp, hc,
+                                                   mask, sums, dloss, (T*)dpred, B, L, C, img, p, norm_pix));
   return pm_check_launch();
 }

@@ -199,6 +199,15 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(nvec << 2) + threadIdx.x] = (T)src[(nvec << 2) + threadIdx.x];
 }
 
+// out = dy * gelu_erf'(pre): the backward of timm Mlp.act as a stand-alone elementwise pass (the training step gets it from the
+// dfc2 GEMM's PM_EPI_DGELU epilogue; this is for callers that compose their own blocks from the registered ops)
+template <typename T>
+__global__ __launch_bounds__(256) void dgelu_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, long n) {
+  const long nvec = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256)
+    store4<T>(out + 4 * i, load4<T>(dy + 4 * i) * gelu_erf_grad4(load4<T>(pre + 4 * i)));
+}
+
 // ---------------------------------------------------------------------------------------------
 // fused AdamW (torch.optim.AdamW update rule) + act-typed shadow refresh
 // ---------------------------------------------------------------------------------------------
@@ -232,11 +241,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 // Device-resident hyper-parameters (hipGraph-replayable optimizer step): one 16-float record per param group
 //   [0] lr [1] beta1 [2] beta2 [3] eps [4] weight_decay [5] grad_scale [6] step [7] bc1 [8] rsqrt_bc2
+//   [9] skip (pm_loss_scale_update: this step's gradients hold inf / nan)  [10] 1 / loss scale (0 = no scaler: treated as 1)
 constexpr int kHyperStride = 16;
 __global__ void adamw_tick_kernel(float* __restrict__ hyper, int n_groups) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups) return;
   float* h = hyper + (long)g * kHyperStride;
+  if (h[9] != 0.f) return;  // a skipped step does not count (GradScaler.step: optimizer.step() is not called)
   const float step = h[6] + 1.0f;
   h[6] = step;
   h[7] = (float)(1.0 - pow((double)h[1], (double)step));
@@ -247,7 +258,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, T* __restrict__ shadow, long n,
                                                         const float* __restrict__ hyper) {
-  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], gscale = hyper[5];
+  if (hyper[9] != 0.f) return;  // non-finite gradients under loss scaling: the update is skipped, nothing is touched
+  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4];
+  const float gscale = hyper[5] * (hyper[10] != 0.f ? hyper[10] : 1.0f);
   const float bc1 = hyper[7], rsqrt_bc2 = hyper[8];
   const long nvec = n >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
@@ -310,6 +323,41 @@ __global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// dynamic loss scaling on the device (precision mode fp16): torch.cuda.amp.GradScaler's step() + update()
+// (tc.py:4533-4546, engine_pretrain.py:65-72 through misc.py:252-282) without its host read-back of found_inf
+//   state[0] scale  [1] growth tracker  [2] found_inf of the last step  [3] skipped steps  [4] steps  [5] 1 / scale used
+// ---------------------------------------------------------------------------------------------
+__global__ void loss_scale_update_kernel(float* __restrict__ state, const float* __restrict__ stats, float* __restrict__ hyper,
+                                         int n_groups, float growth, float backoff, int interval) {
+  const float scale = state[0];
+  const float found = (stats[1] + stats[2]) > 0.f ? 1.f : 0.f;
+  const float tracker = state[1];
+  __syncthreads();
+  for (int g = threadIdx.x; g < n_groups; g += blockDim.x) {
+    hyper[(long)g * kHyperStride + 9] = found;
+    hyper[(long)g * kHyperStride + 10] = 1.0f / scale;
+  }
+  if (threadIdx.x == 0) {
+    state[2] = found;
+    state[4] += 1.f;
+    state[5] = 1.0f / scale;
+    if (found != 0.f) {
+      state[0] = scale * backoff;
+      state[1] = 0.f;
+      state[3] += 1.f;
+    } else {
+      const float t = tracker + 1.f;
+      if (t >= (float)interval) {
+        state[0] = scale * growth;
+        state[1] = 0.f;
+      } else {
+        state[1] = t;
+      }
+    }
+  }
+}
+
 inline int cap_grid(long work_items, int per_block, int cap) {
   long g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -327,12 +375,7 @@ extern "C" int pm_colsum_ws(const void* x, long ldx, int dtype, float* out, int 
   const dim3 grid((N + 255) / 256, splits);
   float* partials = (workspace && ws_bytes >= (size_t)splits * N * sizeof(float)) ? reinterpret_cast<float*>(workspace) : nullptr;
   hipStream_t s = pm_stream(stream);
-  if (dtype == PM_BF16)
-    hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, ldx, out, partials, M, N);
-  else if (dtype == PM_F32)
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, out, partials, M, N);
-  else
-    return PM_EINVAL;
+  PM_DISPATCH_ACT(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, s, (const T*)x, ldx, out, partials, M, N));
   if (partials) hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, partials, out, splits, N);
   return pm_check_launch();
 }
@@ -348,12 +391,8 @@ extern "C" int pm_patch_im2col(const float* imgs, const int* ids_keep, void* col
   const int L = (img / p) * (img / p);
   if (keep > L || (!ids_keep && keep != L)) return PM_ESHAPE;
   const dim3 grid(B * keep);
-  if (out_dtype == PM_BF16)
-    hipLaunchKernelGGL(im2col_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), imgs, ids_keep, (__bf16*)cols, C, img, p, keep);
-  else if (out_dtype == PM_F32)
-    hipLaunchKernelGGL(im2col_kernel<float>, grid, dim3(256), 0, pm_stream(stream), imgs, ids_keep, (float*)cols, C, img, p, keep);
-  else
-    return PM_EINVAL;
+  PM_DISPATCH_ACT(out_dtype, T, hipLaunchKernelGGL(im2col_kernel<T>, grid, dim3(256), 0, pm_stream(stream), imgs, ids_keep, (T*)cols,
+                                                   C, img, p, keep));
   return pm_check_launch();
 }
 
@@ -371,12 +410,8 @@ extern "C" int pm_assemble_tokens_bwd(const float* dx, const int* ids_keep, void
   if (!dx || !demb) return PM_EINVAL;
   if (B <= 0 || keep <= 0 || D <= 0 || (D & 3)) return PM_ESHAPE;
   const dim3 grid(cap_grid((long)B * keep, 4, 4096));
-  if (act_dtype == PM_BF16)
-    hipLaunchKernelGGL(assemble_bwd_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), dx, ids_keep, (__bf16*)demb, dpos, B, keep, D);
-  else if (act_dtype == PM_F32)
-    hipLaunchKernelGGL(assemble_bwd_kernel<float>, grid, dim3(256), 0, pm_stream(stream), dx, ids_keep, (float*)demb, dpos, B, keep, D);
-  else
-    return PM_EINVAL;
+  PM_DISPATCH_ACT(act_dtype, T, hipLaunchKernelGGL(assemble_bwd_kernel<T>, grid, dim3(256), 0, pm_stream(stream), dx, ids_keep,
+                                                   (T*)demb, dpos, B, keep, D));
   if (dcls)
     hipLaunchKernelGGL(cls_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, pm_stream(stream), dx, dcls, dpos, B,
                        (long)(keep + 1) * D, D);
@@ -402,12 +437,17 @@ extern "C" int pm_cast(const float* src, void* dst, int dst_dtype, long n, void*
   if (n <= 0) return PM_ESHAPE;
   if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return PM_EALIGN;
   const dim3 grid(cap_grid(n >> 2, 256, 4096));
-  if (dst_dtype == PM_BF16)
-    hipLaunchKernelGGL(cast_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), src, (__bf16*)dst, n);
-  else if (dst_dtype == PM_F32)
-    hipLaunchKernelGGL(cast_kernel<float>, grid, dim3(256), 0, pm_stream(stream), src, (float*)dst, n);
-  else
-    return PM_EINVAL;
+  PM_DISPATCH_ACT(dst_dtype, T, hipLaunchKernelGGL(cast_kernel<T>, grid, dim3(256), 0, pm_stream(stream), src, (T*)dst, n));
+  return pm_check_launch();
+}
+
+extern "C" int pm_dgelu(const void* dy, const void* pre, void* out, int dtype, long n, void* stream) {
+  if (!dy || !pre || !out) return PM_EINVAL;
+  if (n <= 0 || (n & 3)) return PM_ESHAPE;
+  if (((uintptr_t)dy & 7) || ((uintptr_t)pre & 7) || ((uintptr_t)out & 7)) return PM_EALIGN;
+  const dim3 grid(cap_grid(n >> 2, 256, 4096));
+  PM_DISPATCH_ACT(dtype, T, hipLaunchKernelGGL(dgelu_kernel<T>, grid, dim3(256), 0, pm_stream(stream), (const T*)dy, (const T*)pre,
+                                               (T*)out, n));
   return pm_check_launch();
 }
 
@@ -420,14 +460,9 @@ extern "C" int pm_adamw(float* p, const float* g, float* m, float* v, void* shad
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float rsqrt_bc2 = (float)(1.0 / sqrt(bc2));
   const dim3 grid(cap_grid(n >> 2, 256, 4096));
-  if (!shadow || shadow_dtype == PM_BF16)
-    hipLaunchKernelGGL(adamw_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), p, g, m, v, (__bf16*)shadow, n, lr, beta1,
-                       beta2, eps, weight_decay, (float)bc1, rsqrt_bc2, grad_scale);
-  else if (shadow_dtype == PM_F32)
-    hipLaunchKernelGGL(adamw_kernel<float>, grid, dim3(256), 0, pm_stream(stream), p, g, m, v, (float*)shadow, n, lr, beta1,
-                       beta2, eps, weight_decay, (float)bc1, rsqrt_bc2, grad_scale);
-  else
-    return PM_EINVAL;
+  if (!shadow) shadow_dtype = PM_BF16;
+  PM_DISPATCH_ACT(shadow_dtype, T, hipLaunchKernelGGL(adamw_kernel<T>, grid, dim3(256), 0, pm_stream(stream), p, g, m, v, (T*)shadow, n,
+                                                      lr, beta1, beta2, eps, weight_decay, (float)bc1, rsqrt_bc2, grad_scale));
   return pm_check_launch();
 }
 
@@ -444,12 +479,18 @@ extern "C" int pm_adamw_dev(float* p, const float* g, float* m, float* v, void* 
   if (!p || !g || !m || !v || !hyper) return PM_EINVAL;
   if (n <= 0 || (n & 3)) return PM_ESHAPE;
   const dim3 grid(cap_grid(n >> 2, 256, 4096));
-  if (!shadow || shadow_dtype == PM_BF16)
-    hipLaunchKernelGGL(adamw_dev_kernel<__bf16>, grid, dim3(256), 0, pm_stream(stream), p, g, m, v, (__bf16*)shadow, n, hyper);
-  else if (shadow_dtype == PM_F32)
-    hipLaunchKernelGGL(adamw_dev_kernel<float>, grid, dim3(256), 0, pm_stream(stream), p, g, m, v, (float*)shadow, n, hyper);
-  else
-    return PM_EINVAL;
+  if (!shadow) shadow_dtype = PM_BF16;
+  PM_DISPATCH_ACT(shadow_dtype, T, hipLaunchKernelGGL(adamw_dev_kernel<T>, grid, dim3(256), 0, pm_stream(stream), p, g, m, v, (T*)shadow,
+                                                      n, hyper));
+  return pm_check_launch();
+}
+
+extern "C" int pm_loss_scale_update(float* state, const float* stats, float* hyper, int n_groups, float growth_factor,
+                                    float backoff_factor, int growth_interval, void* stream) {
+  if (!state || !stats || !hyper) return PM_EINVAL;
+  if (n_groups <= 0 || growth_interval <= 0 || !(growth_factor >= 1.f) || !(backoff_factor > 0.f && backoff_factor <= 1.f)) return PM_ESHAPE;
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, pm_stream(stream), state, stats, hyper, n_groups,
+                     growth_factor, backoff_factor, growth_interval);
   return pm_check_launch();
 }
 
@@ -474,7 +515,8 @@ extern "C" const char* pm_strerror(int status) {
 }
 
 // 3: pm_gemm_ex / pm_gemm_opts replace pm_tune, workspace queries, pm_vit_head_*, pm_supervised_loss_fwd, pm_scale
-extern "C" int pm_abi_version(void) { return 9; }
+// 10: PM_F16 (precision mode fp16), pm_loss_scale_update, pm_dgelu
+extern "C" int pm_abi_version(void) { return 10; }
 
 extern "C" size_t pm_workspace_bytes(int kind, int M, int N) {
   if (M <= 0 || N <= 0) return 0;

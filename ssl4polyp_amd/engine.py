@@ -25,7 +25,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import EPI_ACCUM, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, EPI_STORE, PM_BF16, PM_F32
+from ._lib import EPI_ACCUM, EPI_DGELU, EPI_GELU, EPI_RESIDUAL, EPI_STORE, PM_BF16, PM_F16, PM_F32
 
 LN_EPS = 1e-6  # models_mae.py:227, models.py:164: partial(nn.LayerNorm, eps=1e-6)
 
@@ -83,17 +83,24 @@ def reserve_streams(device) -> None:
     torch.cuda.synchronize(dev)
 
 
+# precision mode -> (activation / matrix-shadow dtype, its C-ABI code).  bf16: v_mfma_f32_32x32x16_bf16, no loss scaling.
+# fp16: the reference's own AMP arithmetic (torch.cuda.amp.autocast = fp16 matmuls with f32 accumulation + GradScaler:
+# train_classification.py:4527-4546, engine_pretrain.py:52-72) on v_mfma_f32_32x32x16_f16 -- same rate, 11 significant bits per
+# operand instead of 8 (logits 4x closer to the fp32 path, gradients 7x: profiles/r4_rounding_fp16_*.json); the backward runs on
+# fp16 operands too, so the loss must be scaled (optim.LossScaler, or torch's GradScaler).  fp32: exact-f32 MFMA, 1/16 of the rate.
+PRECISIONS = {"bf16": (torch.bfloat16, PM_BF16), "fp16": (torch.float16, PM_F16), "fp32": (torch.float32, PM_F32)}
+
+
 class Kernels:
     """Thin typed wrappers: torch tensors in, C-ABI calls out (include/polypmae.h)."""
 
     def __init__(self, precision: str, eps: float = LN_EPS):
         self.eps = float(eps)
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
         self.lib = _lib.load()
         self.precision = precision
-        self.act_dtype = torch.bfloat16 if precision == "bf16" else torch.float32
-        self.act = PM_BF16 if precision == "bf16" else PM_F32
+        self.act_dtype, self.act = PRECISIONS[precision]
 
     # -- helpers ------------------------------------------------------------------------------
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, M, D):

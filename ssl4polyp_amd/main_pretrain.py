@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import models
-from .optim import FusedAdamW, add_weight_decay
+from .optim import FusedAdamW, LossScaler, add_weight_decay
 from .parallel import DataParallel
 from .train import SyntheticLoader, load_mae_checkpoint, save_mae_checkpoint, train_one_epoch_mae
 
@@ -46,7 +46,8 @@ def get_args_parser():
     p.add_argument("--seed", default=0, type=int)
     p.add_argument("--resume", default="")
     p.add_argument("--start_epoch", default=0, type=int)
-    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
+                   help="fp16 = the reference's `--precision amp` arithmetic (fp16 matmuls, f32 accumulation, dynamic loss scaling)")
     p.add_argument("--synthetic", default=0, type=int, help="number of synthetic batches per epoch")
     p.add_argument("--save_every", default=1, type=int)
     p.add_argument("--log_every", default=20, type=int)
@@ -73,15 +74,16 @@ def run(args, data_loader=None):
     opt = FusedAdamW(model, add_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95), overlap_forward=True)
     opt.grad_sync = ddp.sync
     opt.grad_scale = 1.0 / world
+    scaler = LossScaler() if args.precision == "fp16" else None  # main_pretrain.py:219: loss_scaler = NativeScaler()
     if args.resume:  # (DataParallel() above already bound the parameters to the flat device storage)
-        args.start_epoch = load_mae_checkpoint(args.resume, model, opt, args)
+        args.start_epoch = load_mae_checkpoint(args.resume, model, opt, args, loss_scaler=scaler)
     if data_loader is None:
         if args.synthetic <= 0:
             raise SystemExit("no data: pass --synthetic N or call run(args, data_loader)")
         data_loader = SyntheticLoader(args.batch_size, args.synthetic, device, args.input_size, seed=1234 + rank, fresh=True)
     log_path = os.path.join(args.output_dir, "log.txt")
     for epoch in range(args.start_epoch, args.epochs):
-        stats = train_one_epoch_mae(ddp, data_loader, opt, device, epoch, args, log_every=args.log_every,
+        stats = train_one_epoch_mae(ddp, data_loader, opt, device, epoch, args, log_every=args.log_every, loss_scaler=scaler,
                                     printer=(lambda r: print(f"epoch {epoch} {json.dumps(r)}", flush=True)) if rank == 0 else None)
         if rank == 0:
             os.makedirs(args.output_dir, exist_ok=True)
@@ -89,7 +91,8 @@ def run(args, data_loader=None):
                 f.write(json.dumps({"train_loss": stats.loss, "train_lr": stats.lr, "epoch": epoch,
                                     "samples_per_sec": stats.samples_per_sec}) + "\n")
         if (epoch + 1) % args.save_every == 0 or epoch + 1 == args.epochs:
-            save_mae_checkpoint(os.path.join(args.output_dir, "ckpts"), epoch, model, opt, args)
+            save_mae_checkpoint(os.path.join(args.output_dir, "ckpts"), epoch, model, opt, args,
+                                scaler_state=scaler.state_dict() if scaler is not None else None)
     if world > 1:
         dist.destroy_process_group()
     return model, opt

@@ -48,7 +48,7 @@ def _rt(handle: int):
 
 def _k(t_or_dtype, eps: float = 1e-6) -> Kernels:
     dt = t_or_dtype.dtype if torch.is_tensor(t_or_dtype) else t_or_dtype
-    key = ("bf16" if dt == torch.bfloat16 else "fp32", float(eps))
+    key = ("bf16" if dt == torch.bfloat16 else "fp16" if dt == torch.float16 else "fp32", float(eps))
     k = _KERNELS.get(key)
     if k is None:
         k = _KERNELS[key] = Kernels(key[0], key[1])
@@ -100,11 +100,11 @@ _impl("supervised_loss", _supervised_loss)
 # ---------------------------------------------------------------------------------------------------------------------
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, bf16_out):
+    def forward(ctx, x, gamma, beta, eps, bf16_out, out_dtype=None):
         x = x.contiguous().float()
         D = x.shape[-1]
         M = x.numel() // D
-        k = _k(torch.bfloat16 if bf16_out else torch.float32, eps)
+        k = _k(out_dtype if out_dtype is not None else (torch.bfloat16 if bf16_out else torch.float32), eps)
         y = torch.empty(x.shape, dtype=k.act_dtype, device=x.device)
         mean = torch.empty(M, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
@@ -123,7 +123,7 @@ class _LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg, db = torch.zeros(D, device=x.device), torch.zeros(D, device=x.device)
         k.layernorm_bwd(dy, x, gamma.float().contiguous(), mean, rstd, None, dx, None, dg, db, None, M, D)
-        return dx, dg, db, None, None
+        return dx, dg, db, None, None, None
 
 
 class _LinearFn(torch.autograd.Function):
@@ -160,12 +160,10 @@ class _LinearFn(torch.autograd.Function):
         M, N = x.numel() // K, W.shape[0]
         dres = dy if ctx.mode == EPI_RESIDUAL else None
         dy = dy.contiguous().to(x.dtype)
-        if ctx.mode == EPI_GELU:  # dy * gelu'(pre-activation): an identity-free pass through the dGELU epilogue needs a GEMM,
-            # so do it as the elementwise product of the saved pre-activation's derivative (torch, off the hot path)
-            pre = aux.float().requires_grad_(True)
-            with torch.enable_grad():
-                torch.nn.functional.gelu(pre).backward(dy.float())
-            dy = pre.grad.to(x.dtype)
+        if ctx.mode == EPI_GELU:  # dy * gelu'(saved pre-activation): one elementwise HIP pass (pm_dgelu)
+            dact = torch.empty_like(dy)
+            _lib.check(k.lib.pm_dgelu(_ptr(dy), _ptr(aux), _ptr(dact), _lib.dtype_code(dy.dtype), dy.numel(), _stream()), "pm_dgelu")
+            dy = dact
         dx = torch.empty_like(x)
         k.linear_dgrad(dy, W, dx, M, N, K)
         dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
@@ -204,12 +202,12 @@ class _AttentionFn(torch.autograd.Function):
         return dqkv, None
 
 
-_DEF.define("layernorm(Tensor x, Tensor gamma, Tensor beta, float eps=1e-6, bool bf16_out=True) -> Tensor")
+_DEF.define("layernorm(Tensor x, Tensor gamma, Tensor beta, float eps=1e-6, bool bf16_out=True, ScalarType? out_dtype=None) -> Tensor")
 _DEF.define("linear_bias(Tensor x, Tensor weight, Tensor? bias) -> Tensor")
 _DEF.define("linear_bias_gelu(Tensor x, Tensor weight, Tensor? bias) -> Tensor")
 _DEF.define("linear_bias_residual(Tensor x, Tensor weight, Tensor? bias, Tensor residual) -> Tensor")
 _DEF.define("attention(Tensor qkv, int heads) -> Tensor")
-_impl("layernorm", lambda x, g, b, eps=1e-6, bf16_out=True: _LayerNormFn.apply(x, g, b, float(eps), bool(bf16_out)))
+_impl("layernorm", lambda x, g, b, eps=1e-6, bf16_out=True, out_dtype=None: _LayerNormFn.apply(x, g, b, float(eps), bool(bf16_out), out_dtype))
 _impl("linear_bias", lambda x, w, b: _LinearFn.apply(x, w, b, None, EPI_STORE))
 _impl("linear_bias_gelu", lambda x, w, b: _LinearFn.apply(x, w, b, None, EPI_GELU))
 _impl("linear_bias_residual", lambda x, w, b, r: _LinearFn.apply(x, w, b, r, EPI_RESIDUAL))

@@ -140,7 +140,11 @@ class FusedAdamW(torch.optim.Optimizer):
             self._hyper_host = rows
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, loss_scaler: "Optional[LossScaler]" = None):
+        """loss_scaler: the gradients carry its loss scale (precision mode fp16).  The update then starts with one statistics
+        pass over them and `pm_loss_scale_update` -- found_inf, the skip flag and 1/scale go into the device-side hyper records,
+        the scale moves (GradScaler.step + update, train_classification.py:4545-4546) -- and `pm_adamw_dev` unscales inside
+        the update or returns untouched on a non-finite step: no host read-back anywhere."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -160,6 +164,11 @@ class FusedAdamW(torch.optim.Optimizer):
             group["step"] = int(group.get("step", 0)) + 1  # host mirror (the device record is authoritative)
             for r, lo, hi in self._segments(f, group):
                 work.append((gi, r, lo, hi))
+        scaled = loss_scaler is not None and loss_scaler.enabled
+        stat_segs = [(r, lo, hi) for _, r, lo, hi in work] if scaled else []
+        if not scaled and getattr(self, "_scaler_used", False):  # a scaler was dropped: clear its skip flag / unscale factor
+            self._hyper[:, 9:11] = 0.0
+            self._scaler_used = False
         if overlap:
             # forward order: vectors first, then the matrices by offset, cut at the block boundaries so that the next
             # forward can start on block 0 while the later blocks are still being updated
@@ -181,6 +190,15 @@ class FusedAdamW(torch.optim.Optimizer):
         else:
             stream_ctx = contextlib.nullcontext()
         with stream_ctx:
+            if scaled:
+                state, stats = loss_scaler._device_state(f.device)
+                stats.zero_()
+                for r, lo, hi in stat_segs:
+                    _lib.check(lib.pm_grad_stats(_ptr(f.G[r][lo:hi]), hi - lo, _ptr(stats), _stream()), "pm_grad_stats")
+                _lib.check(lib.pm_loss_scale_update(_ptr(state), _ptr(stats), _ptr(self._hyper), len(self.param_groups),
+                                                    loss_scaler.growth_factor, loss_scaler.backoff_factor,
+                                                    loss_scaler.growth_interval, _stream()), "pm_loss_scale_update")
+                self._scaler_used = True
             _lib.check(lib.pm_adamw_tick(_ptr(self._hyper), len(self.param_groups), _stream()), "pm_adamw_tick")
             for gi, r, lo, hi in work:
                 shadow = f.S[lo:hi] if (r == "mat" and f.S is not None) else None
@@ -256,3 +274,121 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._V[r][lo:lo + n].copy_(st["exp_avg_sq"].reshape(-1))
                 group["step"] = int(float(st["step"]))
         self._hyper = None  # rebuild the device records (incl. the step counters) at the next step()
+
+
+class _ScaleLossFn(torch.autograd.Function):
+    """loss * scale and d loss * scale, the scale read from DEVICE memory by the kernel (pm_scale): no host value is baked in."""
+
+    @staticmethod
+    def forward(ctx, loss, scale):
+        lib = _lib.load()
+        x = loss.reshape(1).contiguous().float()
+        out = torch.empty_like(x)
+        _lib.check(lib.pm_scale(_ptr(x), _ptr(scale), _ptr(out), 1, _stream()), "pm_scale")
+        ctx.scale = scale
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        d = dout.reshape(1).contiguous().float()
+        out = torch.empty_like(d)
+        _lib.check(lib.pm_scale(_ptr(d), _ptr(ctx.scale), _ptr(out), 1, _stream()), "pm_scale")
+        return out.reshape(()), None
+
+
+class LossScaler:
+    """Dynamic loss scaling for precision mode "fp16", resident on the device.
+
+    Same surface and arithmetic as the ``torch.cuda.amp.GradScaler`` of the reference's AMP loops
+    (train_classification.py:4533-4546: ``scaler.scale(loss).backward(); scaler.unscale_(opt); scaler.step(opt); scaler.update()``;
+    engine_pretrain.py:65-72 through mae/util/misc.py:252-282), same defaults (65536, x2 after 2000 clean steps, x0.5 after a
+    non-finite one).  Different mechanics: GradScaler.step reads ``found_inf`` back to the host before it decides whether to call
+    ``optimizer.step()`` -- one pipeline drain per step; here the decision, the unscaling and the scale update are three device
+    kernels inside ``FusedAdamW.step`` (one statistics pass, ``pm_loss_scale_update``, then an AdamW that multiplies by
+    1/scale or returns untouched), so the host never waits.  ``unscale_`` is therefore a no-op kept for call-compatibility:
+    the flat gradients stay scaled, ``unscaled_grad_stats`` gives the reference's logged norms.
+    torch's own GradScaler also works with these models and FusedAdamW (the backward is linear in the loss gradient)."""
+
+    def __init__(self, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000, enabled: bool = True):
+        self.init_scale, self.growth_factor, self.backoff_factor = float(init_scale), float(growth_factor), float(backoff_factor)
+        self.growth_interval, self.enabled = int(growth_interval), bool(enabled)
+        self._state: Optional[torch.Tensor] = None   # f32[8] on the device: pm_loss_scale_update's record
+        self._stats: Optional[torch.Tensor] = None   # f32[3]: sum g^2, #NaN, #Inf of the last step's scaled gradients
+        self._pending: Optional[dict] = None         # a state dict loaded before the device is known
+
+    def _device_state(self, device):
+        if self._state is None or self._state.device != torch.device(device):
+            st = torch.zeros(8, dtype=torch.float32)
+            st[0] = self.init_scale
+            if self._pending is not None:
+                st[0], st[1] = float(self._pending["scale"]), float(self._pending.get("_growth_tracker", 0))
+                self._pending = None
+            self._state = st.to(device)
+            self._stats = torch.zeros(3, dtype=torch.float32, device=device)
+        return self._state, self._stats
+
+    def scale(self, loss: torch.Tensor) -> torch.Tensor:
+        if not self.enabled:
+            return loss
+        state, _ = self._device_state(loss.device)
+        return _ScaleLossFn.apply(loss, state[0:1])
+
+    def unscale_(self, optimizer) -> None:
+        """No-op: FusedAdamW unscales inside its update (see the class comment)."""
+
+    def step(self, optimizer, *args, **kwargs):
+        if not isinstance(optimizer, FusedAdamW):
+            raise _lib.PolypMaeError("LossScaler.step needs ssl4polyp_amd.optim.FusedAdamW (the skip / unscale decision runs inside "
+                                     "its device kernels); use torch.cuda.amp.GradScaler with other optimizers")
+        return optimizer.step(*args, loss_scaler=self if self.enabled else None, **kwargs)
+
+    def update(self, new_scale: Optional[float] = None) -> None:
+        """The scale already moved inside step() (device side).  new_scale: set it explicitly, as GradScaler.update does."""
+        if new_scale is not None and self._state is not None:
+            self._state[0] = float(new_scale)
+            self._state[1] = 0.0
+
+    def unscaled_grad_stats(self, optimizer) -> torch.Tensor:
+        """[sum(g^2), #NaN, #Inf] of the UNSCALED gradients (device tensor, no host sync): what the reference logs after
+        scaler.unscale_ (train_classification.py:4535-4544)."""
+        gs = optimizer.grad_stats()
+        if self.enabled and self._state is not None:
+            gs[0] = gs[0] / (self._state[0] * self._state[0])
+        return gs
+
+    # -- host-side views (each is one device read-back: logging / checkpoints only) -------------------------------------------
+    def get_scale(self) -> float:
+        if not self.enabled:
+            return 1.0
+        if self._state is None:
+            return float(self._pending["scale"]) if self._pending is not None else self.init_scale
+        return float(self._state[0])
+
+    def counters(self) -> dict:
+        """{"steps", "skipped", "found_inf_last"} since construction."""
+        if self._state is None:
+            return {"steps": 0, "skipped": 0, "found_inf_last": False}
+        v = self._state.tolist()
+        return {"steps": int(v[4]), "skipped": int(v[3]), "found_inf_last": bool(v[2])}
+
+    def state_dict(self) -> dict:
+        """torch.cuda.amp.GradScaler's layout (what the reference's checkpoints store: misc.py:311-318, tc.py:7036-7067)."""
+        if not self.enabled:
+            return {}
+        tracker = int(self._state[1]) if self._state is not None else int((self._pending or {}).get("_growth_tracker", 0))
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": tracker}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if not sd:
+            return
+        self.growth_factor = float(sd.get("growth_factor", self.growth_factor))
+        self.backoff_factor = float(sd.get("backoff_factor", self.backoff_factor))
+        self.growth_interval = int(sd.get("growth_interval", self.growth_interval))
+        if self._state is not None:
+            self._state[0] = float(sd["scale"])
+            self._state[1] = float(sd.get("_growth_tracker", 0))
+        else:
+            self._pending = dict(sd)

@@ -143,9 +143,15 @@ def _flush(stats: EpochStats, acc: torch.Tensor, gstats: Optional[torch.Tensor],
 
 
 def train_one_epoch_mae(model, data_loader: Iterable, optimizer, device, epoch: int, args, log_every: int = 20,
-                        printer: Optional[Callable] = print, grad_stats: bool = True) -> EpochStats:
+                        printer: Optional[Callable] = print, grad_stats: bool = True, loss_scaler=None) -> EpochStats:
     """engine_pretrain.py:22-100.  `model(samples, mask_ratio=...) -> (loss, pred, mask)`; `args` needs lr, min_lr,
-    warmup_epochs, epochs, accum_iter, mask_ratio.  `model` may be a parallel.DataParallel wrapper."""
+    warmup_epochs, epochs, accum_iter, mask_ratio.  `model` may be a parallel.DataParallel wrapper.
+    loss_scaler: optim.LossScaler for precision mode fp16 (engine_pretrain.py:65-72: loss_scaler.scale(loss).backward();
+    loss_scaler.step(optimizer); loss_scaler.update()) -- None for bf16 / fp32."""
+    scale = loss_scaler.scale if loss_scaler is not None else (lambda x: x)
+    opt_step = (lambda: (loss_scaler.step(optimizer), loss_scaler.update())) if loss_scaler is not None else optimizer.step
+    opt_stats = (lambda: loss_scaler.unscaled_grad_stats(optimizer)) if loss_scaler is not None else \
+        getattr(optimizer, "grad_stats", None)
     model.train(True)
     accum = max(int(getattr(args, "accum_iter", 1)), 1)
     optimizer.zero_grad(set_to_none=True)
@@ -166,16 +172,16 @@ def train_one_epoch_mae(model, data_loader: Iterable, optimizer, device, epoch: 
         if no_sync is not None and not last_micro:
             with no_sync():
                 loss, _, _ = model(samples, mask_ratio=args.mask_ratio)
-                (loss / accum).backward()
+                scale(loss / accum).backward()
         else:
             loss, _, _ = model(samples, mask_ratio=args.mask_ratio)
-            (loss / accum).backward()
+            scale(loss / accum).backward()
         acc[0] += loss.detach()
         acc[1] += 1.0
         if last_micro:
-            if grad_stats and hasattr(optimizer, "grad_stats") and (it // accum + 1) % log_every == 0:
-                gs = optimizer.grad_stats()
-            optimizer.step()
+            if grad_stats and opt_stats is not None and (it // accum + 1) % log_every == 0:
+                gs = opt_stats()
+            opt_step()
             optimizer.zero_grad(set_to_none=True)
         stats.steps += 1
         stats.samples += samples.shape[0] * _world()
@@ -193,10 +199,16 @@ def train_one_epoch_mae(model, data_loader: Iterable, optimizer, device, epoch: 
 
 def train_epoch_cls(model, train_loader: Iterable, optimizer, device, pos_weight: Optional[torch.Tensor] = None,
                     class_weights: Optional[torch.Tensor] = None, max_batches: Optional[int] = None, log_every: int = 20,
-                    printer: Optional[Callable] = print, grad_stats: bool = True) -> EpochStats:
+                    printer: Optional[Callable] = print, grad_stats: bool = True, loss_scaler=None) -> EpochStats:
     """tc.py:4446-4650 hot loop: zero_grad -> model(data) -> BCE/CE -> backward -> grad norm -> optimizer.step().
-    Batches are (data, target) or (data, target, meta) as produced by the reference's pack_collate."""
+    Batches are (data, target) or (data, target, meta) as produced by the reference's pack_collate.
+    loss_scaler: optim.LossScaler for precision mode fp16 (tc.py:4533-4546: scaler.scale(loss).backward(); scaler.unscale_;
+    grad norms; scaler.step(optimizer); scaler.update()) -- None for bf16 / fp32."""
     model.train(True)
+    scale = loss_scaler.scale if loss_scaler is not None else (lambda x: x)
+    opt_step = (lambda: (loss_scaler.step(optimizer), loss_scaler.update())) if loss_scaler is not None else optimizer.step
+    opt_stats = (lambda: loss_scaler.unscaled_grad_stats(optimizer)) if loss_scaler is not None else \
+        getattr(optimizer, "grad_stats", None)
     stats = EpochStats()
     acc = torch.zeros(2, dtype=torch.float32, device=device)
     total, count = 0.0, 0.0
@@ -212,10 +224,10 @@ def train_epoch_cls(model, train_loader: Iterable, optimizer, device, pos_weight
         optimizer.zero_grad(set_to_none=True)
         output = model(data)
         loss = supervised_loss(output, target, pos_weight, class_weights)
-        loss.backward()
-        if grad_stats and hasattr(optimizer, "grad_stats") and (it + 1) % log_every == 0:
-            gs = optimizer.grad_stats()
-        optimizer.step()
+        scale(loss).backward()
+        if grad_stats and opt_stats is not None and (it + 1) % log_every == 0:
+            gs = opt_stats()
+        opt_step()
         acc[0] += loss.detach()
         acc[1] += 1.0
         stats.steps += 1
@@ -488,8 +500,8 @@ def save_mae_checkpoint(output_dir, epoch: int, model, optimizer, args, scaler_s
     return path
 
 
-def load_mae_checkpoint(path, model, optimizer=None, args=None) -> int:
-    """misc.py:338-352: restores model (+ optimizer and start epoch).  Returns the next epoch to run."""
+def load_mae_checkpoint(path, model, optimizer=None, args=None, loss_scaler=None) -> int:
+    """misc.py:338-352: restores model (+ optimizer, loss scaler and start epoch).  Returns the next epoch to run."""
     ckpt = torch.load(str(path), map_location="cpu", weights_only=False)
     _unwrap(model).load_state_dict(ckpt["model"])
     start = 0
@@ -498,6 +510,8 @@ def load_mae_checkpoint(path, model, optimizer=None, args=None) -> int:
         start = int(ckpt["epoch"]) + 1
         if args is not None:
             args.start_epoch = start
+        if loss_scaler is not None and "scaler" in ckpt:  # misc.py:349-350
+            loss_scaler.load_state_dict(ckpt["scaler"])
     return start
 
 

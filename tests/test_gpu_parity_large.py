@@ -23,7 +23,15 @@ DEV = "cuda"
 TOL = {  # logits max-rel, loss rel, pred rel-L2, grad rel-L2
     "fp32": dict(logits=1e-3, loss=1e-3, pred=1e-2, grad=1e-2),
     "bf16": dict(logits=2e-2, loss=1e-3, pred=1e-2, grad=1e-2, vec=1e-2),   # MAE: SURVEY 8-d as written
+    # precision mode fp16 (round 4; the reference's own AMP arithmetic): SURVEY 8-d AS WRITTEN for loss, pred and every gradient,
+    # classifier and MAE alike.  Logits: the floor of fp16 OPERAND rounding through 12 blocks, measured without any kernel by the
+    # CPU emulation (oracle/vit_bf16_grad_sim.py FP16, profiles/r4_rounding_fp16_cls_*.json), is 1.30e-3 at B = 16 and B = 64 on
+    # the generated weights and 1.63e-3 on a fresh initialisation -- 30-60 % above the north-star's 1e-3, which only more operand
+    # bits can buy (fp32 mode: 2e-6).  The gate is that floor + 25 % (2.0e-3), not the measured kernel + 25 %.
+    "fp16": dict(logits=2.0e-3, loss=1e-3, pred=1e-2, grad=1e-2, vec=1e-2),
 }
+LOSS_SCALE = 4096.0  # fp16: the backward runs on fp16 operands, so the tests scale the loss as the reference's GradScaler does
+# (train_classification.py:4533) and compare grad / LOSS_SCALE; a power of two: scaling and unscaling are exact
 # bf16 classifier: MEASURED on MI355X (round 3, deterministic kernels) + 25 %, per batch size -- not a multiple of a yardstick.
 # What the numbers are made of (profiles/r3_rounding_cost_cls_b{16,64}.json): the CPU emulation of bf16
 # OPERAND rounding alone (oracle/vit_bf16_grad_sim.py, no kernel) gives logits 4.8e-3 / 5.5e-3, gradients 1.1e-2 / 3.9e-2 at
@@ -116,7 +124,7 @@ def _autocast_cls_grad_errors(B):
     return worst
 
 
-def _grad_report(named_params, grads, tol, tag, vec_tol=None):
+def _grad_report(named_params, grads, tol, tag, vec_tol=None, scale=1.0):
     """Weight matrices must meet `tol` (<= 1e-2 rel-L2).  Vector parameters (biases, LayerNorm affine, cls /
     mask tokens) are sums over ALL B x N tokens of activation gradients that the bf16 mode stores in bf16: on random
     data those contributions cancel (|sum| ~ sqrt(#tokens) x rms), so the unbiased 2^-9 rounding of each term shows up
@@ -129,7 +137,7 @@ def _grad_report(named_params, grads, tol, tag, vec_tol=None):
         if n not in grads:
             assert p.grad is None, n
             continue
-        e = rel_l2(p.grad, grads[n])
+        e = rel_l2(p.grad / scale, grads[n])
         if n.endswith("attn.qkv.bias"):
             skipped.append(e)  # q and v thirds are real, the k third is zero: reported only
             continue
@@ -145,7 +153,7 @@ def _grad_report(named_params, grads, tol, tag, vec_tol=None):
 
 
 @pytest.mark.parametrize("B", [16, 64])
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_vitb_classifier_vs_oracle_at_bench_dispatch(B, prec):
     import ssl4polyp_amd as A
     sd, imgs, labels, logits_ref, loss_ref, grads = _oracle_cls(B)
@@ -156,19 +164,21 @@ def test_vitb_classifier_vs_oracle_at_bench_dispatch(B, prec):
     vm.to(DEV)
     logits = vm(imgs.to(DEV))
     loss = A.supervised_loss(logits, labels.to(DEV), pos_weight=1.7)
-    loss.backward()
-    t = TOL[prec] if prec == "fp32" else TOL_CLS_BF16[B]
+    scale = LOSS_SCALE if prec == "fp16" else 1.0
+    (loss * scale).backward()
+    t = TOL_CLS_BF16[B] if prec == "bf16" else TOL[prec]
     e_logits, e_loss = rel(logits, logits_ref), rel(loss, loss_ref)
     print(f"[parity] cls B={B} {prec}: logits max-rel {e_logits:.3e}, loss rel {e_loss:.3e}")
     assert e_logits < t["logits"] and e_loss < t["loss"]
     tol_m, tol_v = t["grad"], t.get("vec")
     if prec == "bf16":
         _autocast_cls_grad_errors(B)  # context only (printed): PyTorch's own bf16 autocast of the oracle; not part of any gate
-    _grad_report(vm.named_parameters(), grads, tol_m, f"cls B={B} {prec}", tol_v)
+    _grad_report(vm.named_parameters(), grads, tol_m, f"cls B={B} {prec}", tol_v, scale=scale)
 
 
 @pytest.mark.parametrize("mode", ["none", "head+1", "head+2"])
-def test_vitb_finetune_freeze_modes_vs_oracle(mode):
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+def test_vitb_finetune_freeze_modes_vs_oracle(mode, prec):
     """C5's fine-tune regimes at ViT-B/16 size (finetune.py:49-91: "none" = linear probe, "head+k" = lin_head + the last k
     blocks; frozen parameters get no gradient): the trainable parameters' gradients must equal the oracle's full-model
     gradients for those parameters (freezing does not change the mathematics), the frozen ones stay None, and linear probe
@@ -176,33 +186,40 @@ def test_vitb_finetune_freeze_modes_vs_oracle(mode):
     import ssl4polyp_amd as A
     B = 16
     sd, imgs, labels, logits_ref, loss_ref, grads = _oracle_cls(B)
-    vm = A.get_MAE_backbone(None, True, 2, False, None, precision="fp32")
+    vm = A.get_MAE_backbone(None, True, 2, False, None, precision=prec)
     sd_mae = dict(sd)
     sd_mae["decoder_pos_embed"] = vm.state_dict()["decoder_pos_embed"]
     vm.load_state_dict(sd_mae)
     vm.to(DEV)
+    # fp32 mode: 1e-3 everywhere (three orders of margin); fp16: SURVEY 8-d as written + the logit floor (TOL); bf16: the B = 16
+    # classifier bounds of the full-model test (the same tensors, fewer of them)
+    t = dict(logits=1e-3, grad=1e-3) if prec == "fp32" else (TOL_CLS_BF16[B] if prec == "bf16" else TOL[prec])
+    scale = LOSS_SCALE if prec == "fp16" else 1.0
     tail = {"none": 0, "head+1": 1, "head+2": 2}[mode]
     keep = tuple(f"blocks.{11 - j}." for j in range(tail)) + ("lin_head.",)
     for n, p in vm.named_parameters():  # what configure_finetune_parameters(model, mode) does
         p.requires_grad_(n.startswith(keep))
     vm.frozen = mode == "none"
     logits = vm(imgs.to(DEV))
-    A.supervised_loss(logits, labels.to(DEV), pos_weight=1.7).backward()
-    assert rel(logits, logits_ref) < 1e-3
-    n_train = 0
+    (A.supervised_loss(logits, labels.to(DEV), pos_weight=1.7) * scale).backward()
+    assert rel(logits, logits_ref) < t["logits"]
+    n_train, worst = 0, 0.0
     for n, p in vm.named_parameters():
         if n.startswith(keep):
-            assert rel_l2(p.grad, grads[n]) < 1e-3 or n.endswith("attn.qkv.bias"), n
+            e = rel_l2(p.grad / scale, grads[n])
+            assert e < t["grad"] or n.endswith("attn.qkv.bias"), (n, e)
+            worst = max(worst, 0.0 if n.endswith("attn.qkv.bias") else e)
             n_train += 1
         else:
             assert p.grad is None, n
     assert n_train == 2 + 12 * tail
+    print(f"[parity] cls B={B} {prec} finetune mode {mode}: logits {rel(logits, logits_ref):.3e}, worst trainable gradient {worst:.3e}")
     if mode == "none":  # forward-only workspace: two block workspaces were pooled, not twelve
         pools = vm._rt.pool
         assert all(len(ws.blocks) <= 2 for lst in pools.values() for ws in lst), {k: [len(w.blocks) for w in v] for k, v in pools.items()}
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_vitb_mae_vs_oracle_at_bench_dispatch(prec):
     """B = 48: encoder M = 2400, decoder M = 9456 -> ring kernels for forward, dgrad and split-K wgrad of both stacks."""
     import ssl4polyp_amd as A
@@ -212,16 +229,17 @@ def test_vitb_mae_vs_oracle_at_bench_dispatch(prec):
     m.load_state_dict(sd)
     m.to(DEV)
     loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
-    loss.backward()
+    scale = LOSS_SCALE if prec == "fp16" else 1.0
+    (loss * scale).backward()
     t = TOL[prec]
     assert torch.equal(mask.cpu(), mask_ref)
     e_loss, e_pred = rel(loss, loss_ref), rel_l2(pred, pred_ref)
     print(f"[parity] mae B={B} {prec}: loss rel {e_loss:.3e}, pred rel-L2 {e_pred:.3e}")
     assert e_loss < t["loss"] and e_pred < t["pred"]
-    _grad_report(m.named_parameters(), grads, t["grad"], f"mae B={B} {prec}", t.get("vec"))
+    _grad_report(m.named_parameters(), grads, t["grad"], f"mae B={B} {prec}", t.get("vec"), scale=scale)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_vitb_mae_fwd_bwd_at_grouped_wgrad_dispatch(prec):
     """B = 64: encoder M = 64 x 50 = 3 200 and decoder M = 64 x 197 = 12 608 are both multiples of the 32-token k-step, so the
     bf16 backward takes the kernels the MAE bench (B = 256) runs: the encoder blocks' FULL-K grouped weight gradients
@@ -235,12 +253,13 @@ def test_vitb_mae_fwd_bwd_at_grouped_wgrad_dispatch(prec):
     m.load_state_dict(sd)
     m.to(DEV)
     loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
-    loss.backward()
+    scale = LOSS_SCALE if prec == "fp16" else 1.0
+    (loss * scale).backward()
     rt = m._rt
     k = rt.k
     enc_dims = ((768, 3072), (3072, 768), (768, 768), (2304, 768))
     dec_dims = ((512, 2048), (2048, 512), (512, 512), (1536, 512))
-    if prec == "bf16":
+    if prec != "fp32":
         import ctypes
         from ssl4polyp_amd import _lib
         assert k.can_group_wgrad(B * 50, enc_dims) and k.can_group_wgrad(B * 197, dec_dims)
@@ -248,7 +267,7 @@ def test_vitb_mae_fwd_bwd_at_grouped_wgrad_dispatch(prec):
         def plan(K, dims):
             arr = (_lib.WgradItem * 4)(*[_lib.WgradItem(64, o, 64, i, 64, i, o, i, 0, None) for o, i in dims])
             t, sl = ctypes.c_int(0), ctypes.c_int(0)
-            assert k.lib.pm_wgrad_group_plan(arr, 4, K, _lib.PM_BF16, None, ctypes.byref(t), ctypes.byref(sl)) == 0
+            assert k.lib.pm_wgrad_group_plan(arr, 4, K, k.act, None, ctypes.byref(t), ctypes.byref(sl)) == 0
             return t.value, sl.value
         assert plan(B * 50, enc_dims) == (108, 1)           # full-K tiles, no slabs
         t_d, s_d = plan(B * 197, dec_dims)
@@ -268,7 +287,7 @@ def test_vitb_mae_fwd_bwd_at_grouped_wgrad_dispatch(prec):
     e_loss, e_pred = rel(loss, loss_ref), rel_l2(pred, pred_ref)
     print(f"[parity] mae B={B} {prec}: loss rel {e_loss:.3e}, pred rel-L2 {e_pred:.3e}")
     assert e_loss < t["loss"] and e_pred < t["pred"]
-    _grad_report(m.named_parameters(), grads, t["grad"], f"mae B={B} {prec}", t.get("vec"))
+    _grad_report(m.named_parameters(), grads, t["grad"], f"mae B={B} {prec}", t.get("vec"), scale=scale)
 
 
 def test_vitb_mae_full_batch_gradients_vs_reference_fixture(golden):
@@ -286,15 +305,19 @@ def test_vitb_mae_full_batch_gradients_vs_reference_fixture(golden):
     sd = O.generated_state_dict(cfg, int(fx["weight_seed"]), decoder=True, n_class=None)
     imgs, _, noise = O.generated_batch(cfg, B, int(fx["batch_seed"]))
     res = {}
-    for prec in ("bf16", "fp32"):
+    for prec in ("bf16", "fp16", "fp32"):
         m = A.mae_vit_base_patch16(norm_pix_loss=False, precision=prec)
         m.load_state_dict(sd)
         m.to(DEV)
         loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
-        loss.backward()
+        scale = LOSS_SCALE if prec == "fp16" else 1.0
+        (loss * scale).backward()
         assert np.array_equal(mask.sum(1).cpu().numpy().astype(np.int32), fx["mask_rowsum"])
         assert np.array_equal(mask[:4].cpu().numpy().astype(np.uint8), fx["mask_first_rows"])
         params = dict(m.named_parameters())
+        for p_ in params.values():  # (unscale in place: the comparisons below read .grad)
+            if p_.grad is not None and scale != 1.0:
+                p_.grad.div_(scale)
         e_loss = abs(float(loss) - float(fx["loss"])) / abs(float(fx["loss"]))
         norms = {n: float(params[n].grad.double().norm()) for n in fx["grad_names"]}
         e_norm = {n: abs(norms[n] - w) / w for n, w in zip(fx["grad_names"], fx["grad_norms"]) if not n.endswith("attn.qkv.bias")}
@@ -310,22 +333,24 @@ def test_vitb_mae_full_batch_gradients_vs_reference_fixture(golden):
         torch.cuda.empty_cache()
     # fp32 mode: the north-star tolerance with room to spare; bf16: SURVEY 8-d (loss 1e-3, gradients 1e-2 rel-L2)
     assert res["fp32"][0] < 1e-5 and max(res["fp32"][1:]) < 1e-3, res["fp32"]
-    assert res["bf16"][0] < 1e-3 and res["bf16"][1] < 1e-2 and res["bf16"][2] < 1e-2 and res["bf16"][3] < 1e-2, res["bf16"]
+    for prec in ("bf16", "fp16"):
+        assert res[prec][0] < 1e-3 and res[prec][1] < 1e-2 and res[prec][2] < 1e-2 and res[prec][3] < 1e-2, (prec, res[prec])
 
 
-def test_vitb_mae_forward_loss_at_full_batch():
-    """The benchmarked MAE configuration itself (C3: B = 256, bf16): forward + loss against the oracle."""
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_vitb_mae_forward_loss_at_full_batch(prec):
+    """The benchmarked MAE configuration itself (C3: B = 256, bf16 / fp16): forward + loss against the oracle."""
     import ssl4polyp_amd as A
     B = 256
     sd, imgs, noise, loss_ref, pred_ref, mask_ref, _ = _oracle_mae(B, False)
-    m = A.mae_vit_base_patch16(norm_pix_loss=False, precision="bf16")
+    m = A.mae_vit_base_patch16(norm_pix_loss=False, precision=prec)
     m.load_state_dict(sd)
     m.to(DEV)
     with torch.no_grad():
         loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
     assert torch.equal(mask.cpu(), mask_ref)
     e_loss, e_pred = rel(loss, loss_ref), rel_l2(pred, pred_ref)
-    print(f"[parity] mae B={B} bf16 forward: loss rel {e_loss:.3e}, pred rel-L2 {e_pred:.3e}")
+    print(f"[parity] mae B={B} {prec} forward: loss rel {e_loss:.3e}, pred rel-L2 {e_pred:.3e}")
     assert e_loss < 1e-3 and e_pred < 1e-2
 
 
