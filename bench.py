@@ -38,7 +38,7 @@ GFLOP_PER_IMG = {"cls": 105.38, "mae": 58.16}
 FWD_GFLOP_PER_IMG, BLOCK_FWD_GFLOP = 35.13, 2.908
 FINETUNE_GFLOP = {"none": FWD_GFLOP_PER_IMG, "head+1": FWD_GFLOP_PER_IMG + 2 * BLOCK_FWD_GFLOP,
                   "head+2": FWD_GFLOP_PER_IMG + 4 * BLOCK_FWD_GFLOP, "full": 105.38}
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense bf16 MFMA / f32 MFMA
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (same rate), f32 MFMA
 PEAK_HBM_GBPS = 8000.0                         # MI355X_MICROARCH.md: HBM3E
 # AdamW on the side stream beside the next forward: +0.5 % on the fine-tune step and +0.6 % on the MAE step under the final stream
 # layout (scratch/r3_exp31.sh; with a stream set per model and the update sharing a hardware queue it cost the MAE step 1.3 %);
@@ -54,12 +54,18 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=["cls", "mae"], default="cls")
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp16", "fp32"], default="bf16",
+                    help="fp16 = the reference's AMP arithmetic (fp16 MFMA operands, f32 accumulation, device-side dynamic loss scaling)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 64 cls / 256 mae)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-stats", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity block (CPU time)")
-    ap.add_argument("--no-mae", action="store_true", help="cls headline only (no MAE sub-record)")
+    ap.add_argument("--no-mae", action="store_true", help="cls headline only (no MAE sub-records)")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the precision-mode fp16 sub-records (cls bs=64, MAE bs=256)")
+    ap.add_argument("--single-batch", action="store_true",
+                    help="A/B switch: train on ONE resident batch with fixed labels, as rounds 1-3 did (the fine-tune memorises it: "
+                         "loss -> 1e-5, all-zero dlogits in the linear-probe regimes); default: 8 resident image batches x 64 label "
+                         "vectors, a new pairing every step, so that the loss stays O(0.7)")
     ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true",
                     help="SURVEY 8-d protocol in full for the CPU baseline (>=3 warm-up + >=10 timed steps at bs=8 AND bs=64, "
@@ -93,7 +99,7 @@ def parse():
 
 def build(workload, precision, device, world, batch, finetune_mode="full", force_sync=False):
     import ssl4polyp_amd as A
-    from ssl4polyp_amd.optim import FusedAdamW, add_weight_decay
+    from ssl4polyp_amd.optim import FusedAdamW, LossScaler, add_weight_decay
     from ssl4polyp_amd.parallel import DataParallel
     from ssl4polyp_amd.train import configure_finetune_parameters
     torch.manual_seed(0)  # identical init on every rank (then broadcast from rank 0 anyway)
@@ -119,19 +125,32 @@ def build(workload, precision, device, world, batch, finetune_mode="full", force
         opt = FusedAdamW(model, add_weight_decay(model, 0.05), lr=lr, betas=(0.9, 0.95), overlap_forward=OVERLAP_ADAMW["mae"])
     opt.grad_sync = ddp.sync
     opt.grad_scale = 1.0 / world
+    # precision mode fp16: the reference's GradScaler() (tc.py:5973-5974, main_pretrain.py:219), resident on the device
+    opt.loss_scaler = LossScaler() if precision == "fp16" else None
     return model, ddp, opt
 
 
-def make_batch(workload, batch, device, rank):
+N_IMG_BATCHES, N_LABEL_SETS = 8, 64
+
+
+def make_batch(workload, batch, device, rank, pool=False):
+    """SURVEY 8-d synthetic inputs: post-Normalize images N(0, 1), labels Bernoulli(0.5), generator seeded 1234 + rank.
+    pool: 8 resident image batches and 64 label vectors ([64, B]); the step pairs image batch i % 8 with label vector i % 64, so a
+    pairing repeats only every 64 steps and the labels are never learnable (rounds 1-3 trained ONE batch: the fine-tune memorised it
+    within ~100 steps -- loss 1e-5, in the frozen-backbone regimes exactly 0 and with it all-zero dlogits in the timed region)."""
     g = torch.Generator(device=device).manual_seed(1234 + rank)
-    imgs = torch.randn(batch, 3, 224, 224, generator=g, device=device)
-    labels = (torch.rand(batch, generator=g, device=device) < 0.5).long()
+    if not pool:
+        imgs = torch.randn(batch, 3, 224, 224, generator=g, device=device)
+        labels = (torch.rand(batch, generator=g, device=device) < 0.5).long()
+        return imgs, labels
+    imgs = [torch.randn(batch, 3, 224, 224, generator=g, device=device) for _ in range(N_IMG_BATCHES)]
+    labels = (torch.rand(N_LABEL_SETS, batch, generator=g, device=device) < 0.5).long()
     return imgs, labels
 
 
 def make_step(workload, ddp, opt, imgs, labels, lr_every_step=False):
     import ssl4polyp_amd as A
-    pos_weight = torch.tensor(1.0, device=imgs.device)
+    pos_weight = torch.tensor(1.0, device=(imgs[0] if isinstance(imgs, (list, tuple)) else imgs).device)
     base_lr = [g["lr"] for g in opt.param_groups]
     counter = [0]
 
@@ -152,23 +171,43 @@ def make_step(workload, ddp, opt, imgs, labels, lr_every_step=False):
             for g, b in zip(opt.param_groups, base_lr):
                 g["lr"] = b * f
 
+    scaler = getattr(opt, "loss_scaler", None)
+    pooled = isinstance(imgs, (list, tuple))
+    tick = [0]
+
+    def pick(im, lb):
+        if im is not None:          # (--input host: the prefetcher hands the batch over)
+            return im, lb
+        if not pooled:
+            return imgs, labels
+        i = tick[0]
+        tick[0] = i + 1
+        return imgs[i % len(imgs)], labels[i % labels.shape[0]]
+
+    def finish(loss):
+        # tc.py:4533-4546 / engine_pretrain.py:65-72: scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()
+        if scaler is not None:
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+        else:
+            loss.backward()
+            opt.step()
+        return loss
+
     if workload == "cls":
-        def step(imgs=imgs, labels=labels):
+        def step(im=None, lb=None):
+            im, lb = pick(im, lb)
             touch_lr()
             opt.zero_grad(set_to_none=True)
-            logits = ddp(imgs)
-            loss = A.supervised_loss(logits, labels, pos_weight=pos_weight)  # tc.py:3347-3374, 6090-6102 (one HIP launch)
-            loss.backward()
-            opt.step()
-            return loss
+            logits = ddp(im)
+            return finish(A.supervised_loss(logits, lb, pos_weight=pos_weight))  # tc.py:3347-3374, 6090-6102 (one HIP launch)
     else:
-        def step(imgs=imgs, labels=labels):
+        def step(im=None, lb=None):
+            im, lb = pick(im, lb)
             touch_lr()
             opt.zero_grad(set_to_none=True)
-            loss, _, _ = ddp(imgs, mask_ratio=0.75)
-            loss.backward()
-            opt.step()
-            return loss
+            return finish(ddp(im, mask_ratio=0.75)[0])
     return step
 
 
@@ -381,6 +420,13 @@ def cpu_baseline(workload, full):
 # The bf16 classifier numbers are bounded by what bf16 OPERAND ROUNDING alone does to this very configuration, measured in the
 # same block by the CPU emulation (oracle/vit_bf16_grad_sim.py, no kernel involved) + 25 % (+ 1e-3 absolute on the logits).
 HARD_GATES = {"fp32_mode_logits_max_rel": 1e-3, "mae_loss_rel": 1e-3, "mae_pred_rel_l2": 1e-2}
+# precision mode fp16: SURVEY 8-d AS WRITTEN -- loss <= 1e-3, pred and every parameter gradient <= 1e-2 rel-L2 -- and for the logits
+# the floor of fp16 OPERAND rounding through 12 blocks, which no kernel can beat: the CPU emulation (oracle/vit_bf16_grad_sim.py FP16,
+# no kernel involved; profiles/r4_rounding_fp16_cls_*.json) puts it at 1.30e-3 on the tests' generated weights and 1.63e-3 on this
+# bench's fresh initialisation, so the logit gate is 2.0e-3 (floor + 25 %), a fixed number, not derived from what the kernels measure.
+# These ARE hard gates: the process exits non-zero when the fp16 record misses one.
+FP16_GATES = {"logits_max_rel": 2.0e-3, "loss_rel": 1e-3, "weight_grad_rel_l2_worst": 1e-2, "vector_grad_rel_l2_worst": 1e-2}
+PARITY_LOSS_SCALE = 4096.0  # fp16 backward of the parity block: (loss x 2^12).backward(), gradients / 2^12 (exact)
 
 
 _ORACLE_CACHE = {}  # (weights checksum, batch checksum) -> oracle / emulation results of the cls parity block (C5 sub-records)
@@ -420,7 +466,8 @@ def parity_block(workload, model, imgs, labels, precision, light=False):
             logits = model(imgs)
             logits.retain_grad()
             loss = A.supervised_loss(logits, labels, pos_weight=1.0)
-            loss.backward()
+            gscale = PARITY_LOSS_SCALE if precision == "fp16" else 1.0
+            (loss * gscale).backward()
             imgs_c, labels_c = imgs.cpu(), labels.cpu()
 
             def oracle_run(fn):
@@ -455,11 +502,11 @@ def parity_block(workload, model, imgs, labels, precision, light=False):
                     orth[n] = float((a - al[n] * b).norm() / b.norm().clamp_min(1e-300))
                 return errs, mats, vecs, al, orth
 
-            hip_grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+            hip_grads = {n: p.grad / gscale for n, p in model.named_parameters() if p.grad is not None}
             errs, mats, vecs, al, orth = grad_errors(hip_grads)
             wm, wv = max(mats, key=mats.get), max(vecs, key=vecs.get)
             med = lambda d: sorted(d.values())[len(d) // 2]
-            dz_hip = logits.grad.detach().float().cpu()
+            dz_hip = logits.grad.detach().float().cpu() / gscale
             out.update(logits_max_rel=rel(logits.detach(), lr), loss_rel=rel(loss.detach(), lo),
                        dlogits_rel_l2=rel_l2(dz_hip, dz_ref),
                        dlogits_batch_sum_ratio=float(dz_hip[:, 1].double().sum() / dz_ref[:, 1].double().sum()),
@@ -468,12 +515,14 @@ def parity_block(workload, model, imgs, labels, precision, light=False):
                        weight_grad_common_factor_median=med(al), weight_grad_rel_l2_worst_beside_common_factor=max(orth.values()),
                        vector_grad_rel_l2_worst=vecs[wv], vector_grad_rel_l2_worst_name=wv, vector_grad_rel_l2_median=med(vecs),
                        grads_compared=len(errs))
-            if precision == "bf16":
-                # (i) what bf16 operand rounding alone costs HERE, forward and backward, no kernel involved
+            if precision in ("bf16", "fp16"):
+                # (i) what 16-bit operand rounding alone costs HERE, forward and backward, no kernel involved
                 from oracle import vit_bf16_grad_sim as S
-                if "emu" not in cached:
-                    cached["emu"] = oracle_run(lambda p: S.vit_classify(p, imgs_c, cfg))
-                ze, le, dze, ge = cached["emu"]
+                ekey = "emu" if precision == "bf16" else "emu_fp16"
+                if ekey not in cached:
+                    rnd = S.ALL_ON if precision == "bf16" else S.FP16
+                    cached[ekey] = oracle_run(lambda p: S.vit_classify(p, imgs_c, cfg, rnd))
+                ze, le, dze, ge = cached[ekey]
                 if light:  # a C5 regime: the emulation's errors on the parameters THIS mode trains
                     ge = {n: g for n, g in ge.items() if n in hip_grads}
                 _, m_e, v_e, al_e, orth_e = grad_errors(ge)
@@ -481,10 +530,10 @@ def parity_block(workload, model, imgs, labels, precision, light=False):
                        "weight_grad_common_factor_median": med(al_e), "weight_grad_rel_l2_worst_beside_common_factor": max(orth_e.values()),
                        "vector_grad_rel_l2_worst": max(v_e.values()),
                        "dlogits_batch_sum_ratio": float(dze[:, 1].double().sum() / dz_ref[:, 1].double().sum())}
-                out["bf16_emulation"] = {k: float(f"{v:.3e}") for k, v in emu.items()}
-                out["logits_vs_bf16_emulation_max_rel"] = rel(logits.detach(), ze)
+                out[f"{precision}_emulation"] = {k: float(f"{v:.3e}") for k, v in emu.items()}
+                out[f"logits_vs_{precision}_emulation_max_rel"] = rel(logits.detach(), ze)
 
-                if not light:
+                if not light and precision == "bf16":
                     # (ii) PyTorch's own bf16 autocast of the oracle (the reference's AMP path with bf16 in place of fp16)
                     def autocast(p):
                         with torch.autocast("cpu", dtype=torch.bfloat16):
@@ -504,19 +553,27 @@ def parity_block(workload, model, imgs, labels, precision, light=False):
                     out["fp32_mode_logits_max_rel"] = rel(l32, lr)
                     del m32
                     gates["fp32_mode_logits_max_rel"] = HARD_GATES["fp32_mode_logits_max_rel"]
-                gates = {**gates,
-                         "logits_max_rel": 1.25 * emu["logits_max_rel"] + 1e-3,
-                         "weight_grad_rel_l2_worst": 1.25 * emu["weight_grad_rel_l2_worst"] + 1e-3,
-                         "vector_grad_rel_l2_worst": 1.25 * emu["vector_grad_rel_l2_worst"] + 1e-3,
-                         "weight_grad_rel_l2_worst_beside_common_factor": 1.25 * emu["weight_grad_rel_l2_worst_beside_common_factor"] + 1e-3}
+                if precision == "fp16":
+                    gates = dict(FP16_GATES)
+                else:
+                    gates = {**gates,
+                             "logits_max_rel": 1.25 * emu["logits_max_rel"] + 1e-3,
+                             "weight_grad_rel_l2_worst": 1.25 * emu["weight_grad_rel_l2_worst"] + 1e-3,
+                             "vector_grad_rel_l2_worst": 1.25 * emu["vector_grad_rel_l2_worst"] + 1e-3,
+                             "weight_grad_rel_l2_worst_beside_common_factor": 1.25 * emu["weight_grad_rel_l2_worst_beside_common_factor"] + 1e-3}
             else:
                 gates = {"logits_max_rel": 1e-3, "loss_rel": 1e-3, "weight_grad_rel_l2_worst": 1e-2, "vector_grad_rel_l2_worst": 1e-2}
-            out["note"] = ("every gradient of this step is ~ (a direction common to the 64 near-identical noise images) x sum_b dlogit_b, a "
+            if precision == "fp16":
+                out["note"] = ("precision mode fp16 (the reference's AMP arithmetic): gates = SURVEY 8-d as written (loss 1e-3, every gradient "
+                               "1e-2 rel-L2) + the fp16 operand-rounding floor for the logits (emulation 1.63e-3 on this init -> 2.0e-3); "
+                               "`fp16_emulation` = oracle/vit_bf16_grad_sim.py FP16 on the same tensors, no kernel")
+            else:
+                out["note"] = ("every gradient of this step is ~ (a direction common to the 64 near-identical noise images) x sum_b dlogit_b, a "
                            "sum that cancels `dlogits_cancellation`-fold: a coherent logit shift of bf16-rounding size moves it by "
                            "(dlogits_batch_sum_ratio - 1) and every gradient with it (weight_grad_common_factor_median); "
                            "`..._beside_common_factor` is the error orthogonal to the oracle's gradient.  `bf16_emulation` = the same "
-                           "quantities for oracle/vit_bf16_grad_sim.py (bf16 operand rounding on the CPU, no kernel): the gates are "
-                           "1.25 x those + 1e-3; fp32 mode of the same kernels must meet 1e-3.")
+                               "quantities for oracle/vit_bf16_grad_sim.py (bf16 operand rounding on the CPU, no kernel): the gates are "
+                               "1.25 x those + 1e-3; fp32 mode of the same kernels must meet 1e-3.")
         else:
             g = torch.Generator(device=imgs.device).manual_seed(4321)
             noise = torch.rand(imgs.shape[0], 196, device=imgs.device, generator=g)
@@ -535,7 +592,8 @@ def parity_block(workload, model, imgs, labels, precision, light=False):
     out["pass"] = all(ok.values())
     out["failed"] = sorted(k for k, v in ok.items() if not v)
     # the hard gates (exit status): MAE loss / pred, fp32-mode logits
-    hard = ["loss_rel", "pred_rel_l2", "mask_equal"] if workload == "mae" else ["fp32_mode_logits_max_rel"]
+    hard = ["loss_rel", "pred_rel_l2", "mask_equal"] if workload == "mae" else \
+        (list(FP16_GATES) if precision == "fp16" else ["fp32_mode_logits_max_rel"])
     out["hard_fail"] = sorted(k for k in hard if k in ok and not ok[k])
     out["seconds"] = round(time.perf_counter() - t0, 1)
     out = {k: (float(f"{v:.3e}") if isinstance(v, float) and k != "seconds" else v) for k, v in out.items()}
@@ -604,12 +662,83 @@ def torch_baseline(device, batch, steps=10, warmup=3):
                     f"same ViT-B/16 fine-tune step, bs={batch}, {steps} timed steps; context only, not the target"}
 
 
+def held_clock():
+    """The clock the chip holds under THIS step, from the committed in-kernel measurement (profiles/r4_t1_clock_power.json:
+    d(s_memtime) / d(s_memrealtime) stamped inside the GEMM k-loops of the running step -- a diagnostic build, so it cannot be taken
+    live here): the roofline's 2.5 PFLOP/s is 256 CUs x 2.4 GHz; at the held clock the same silicon peaks proportionally lower."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r4_t1_clock_power.json")) as fh:
+            d = json.load(fh)
+        return {"mhz": d["in_kernel_clock"]["cls"]["ring_gemms"]["clock_mhz"]["median"],
+                "source": "profiles/r4_t1_clock_power.json (in-kernel, cls step, ring GEMM k-loops, median over waves)"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def measure_sync(ddp, step, device, n=3):
+    """What the gradient exchange of a data-parallel rank looks like from inside (bench.py --gpus N, or --force-sync at N = 1):
+    bytes and collectives per step from GradSync's launch log, and the EXPOSED wait -- HIP events on the compute stream around the
+    first GradSync.wait() of a step (the end-of-backward callback: everything RCCL had not finished under the backward)."""
+    sync = ddp.sync
+    orig = sync.wait
+    spans = []
+
+    def timed_wait():
+        if not spans or spans[-1][2]:       # first wait of this step (the optimizer's second call is a no-op wait on done work)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig()
+            e1.record()
+            spans.append([e0, e1, False])
+        else:
+            orig()
+
+    sync.wait = timed_wait
+    try:
+        for _ in range(n):
+            step()
+            if spans:
+                spans[-1][2] = True
+        torch.cuda.synchronize(device)
+    finally:
+        sync.wait = orig
+    launched = list(sync.launched)
+    return {"collectives_per_step": len(launched), "allreduce_bytes_per_step": int(4 * sum(hi - lo for _, lo, hi in launched)),
+            "largest_bucket_bytes": int(4 * max((hi - lo for _, lo, hi in launched), default=0)),
+            "exposed_wait_ms": round(sum(e0.elapsed_time(e1) for e0, e1, _ in spans) / max(len(spans), 1), 4),
+            "trainable_bytes": int(sync.trainable_bytes())}
+
+
+def dist_config(world, rank, local, device_name, sync_info, backend):
+    """Self-verification of an N > 1 line (main_pretrain.py:201-214: the reference prints world size and per-rank devices at start-up):
+    what torch.distributed says the world is, every rank's (rank, LOCAL_RANK, device) gathered to rank 0, and rank 0's view of
+    the gradient exchange -- flat scalars / short strings that survive in `config`.  Also the stub's path (BENCH_STUB, CPU test)."""
+    mine = (rank, local, device_name)
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+    else:
+        gathered = [mine]
+    out = {"world_size": dist.get_world_size() if dist.is_initialized() else 1, "backend": backend,
+           "ranks_seen": len({g[0] for g in gathered}), "local_ranks": ",".join(str(g[1]) for g in sorted(gathered)),
+           "devices": "; ".join(f"{g[0]}:{g[2]}" for g in sorted(gathered)),
+           "distinct_local_devices": len({g[1] for g in gathered})}
+    if sync_info:
+        out.update({f"sync_{k}": v for k, v in sync_info.items()})
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
-def run_workload(args, workload, batch, device, world, rank, headline, finetune_mode="full", light=False):
+def run_workload(args, workload, batch, device, world, rank, headline, finetune_mode="full", light=False, precision=None,
+                 kstats=True, eval_forward=None):
     """Build, warm up, time exactly args.steps steps (barrier + synchronize on both sides, max over ranks).
-    light: a C5 sub-record -- no kernel statistics, parity against the cached oracle run of the headline, + eval forward."""
+    light: a C5 sub-record -- no kernel statistics, parity against the cached oracle run of the headline, + eval forward.
+    precision: this record's precision mode (default: --precision); kstats: per-kernel HIP-event statistics."""
+    args = argparse.Namespace(**{**vars(args), "precision": precision or args.precision})
     model, ddp, opt = build(workload, args.precision, device, world, batch, finetune_mode, force_sync=args.force_sync and world == 1)
-    imgs, labels = make_batch(workload, batch, device, rank)
+    imgs, labels = make_batch(workload, batch, device, rank, pool=not args.single_batch)
+    pooled = isinstance(imgs, list)
+    imgs0, labels0 = (imgs[0], labels[0]) if pooled else (imgs, labels)   # the batch of the parity block / the eval forward
     eager_step = make_step(workload, ddp, opt, imgs, labels, args.lr_every_step)
     use_graph = args.graph == "on"  # auto: eager (measured faster: graph replay serialises the wgrad side stream)
     if use_graph:
@@ -637,7 +766,7 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
     # region on a restored copy of them: its ~10 s of CPU oracle leave the GPU idle, and a timed loop that starts right
     # after an idle phase measures the clock ramp (first steps up to 1.5x slower) instead of the steady state.
     want_parity = rank == 0 and world == 1 and not args.no_parity
-    if light:
+    if light or not kstats:
         args = argparse.Namespace(**{**vars(args), "no_kernel_stats": True})
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if want_parity else None
     # Pre-heat: untimed steps of the same step function until args.preheat seconds have passed, so that clocks and power
@@ -682,16 +811,21 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
     # one event per step boundary on the step's own stream: the spread of the per-step times (DVFS ramps, a schedule that
     # settles into a slower phase) is reported beside the mean the metric is computed from
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    losses = []
+    scaler = getattr(opt, "loss_scaler", None)
+    skipped0 = scaler.counters()["skipped"] if scaler is not None else 0
     t0 = time.perf_counter()
     t0_unix = time.time()
     marks[0].record()
     if host_input:
         for i, (im, lb) in enumerate(host_feed(args.steps)):
             loss = step(im, lb)
+            losses.append(loss.detach())
             marks[i + 1].record()
     else:
         for i in range(args.steps):
             loss = step()
+            losses.append(loss.detach())
             marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
@@ -734,6 +868,20 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
     loss_val = float(loss.detach())
     if not (loss_val == loss_val):
         sys.exit(f"non-finite loss in the timed region ({workload}, finetune mode {finetune_mode}, step loss {loss_val})")
+    lv = torch.stack(losses).float().cpu()
+    loss_mean, loss_min = float(lv.mean()), float(lv.min())
+    # a live problem: rounds 1-3 timed a memorised batch (cls loss 1e-5, frozen-backbone regimes 0.0 = all-zero dlogits, i.e. backward
+    # GEMMs on zeros, which hold a higher clock: MI355X_MICROARCH.md DVFS give-back).  A cls record whose loss collapsed is not a
+    # measurement of the training step and is marked as such (the headline fails the run)
+    degenerate = workload == "cls" and loss_min <= 1e-3
+    if degenerate and headline and not args.single_batch:
+        sys.exit(f"degenerate workload: the cls loss fell to {loss_min:.2e} inside the timed region (memorised batch)")
+    scale_info = None
+    if scaler is not None:
+        c = scaler.counters()
+        scale_info = {"loss_scale": scaler.get_scale(), "skipped_steps_in_timed_region": c["skipped"] - skipped0,
+                      "skipped_steps_total": c["skipped"], "optimizer_steps_total": c["steps"]}
+    sync_info = measure_sync(ddp, eager_step, device) if ddp.sync is not None else None
     rec = None
     stats = None
     parity = None
@@ -745,20 +893,20 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
         model._rt.wait_updates()
         torch.cuda.synchronize()
         model.load_state_dict(init_state)  # back to the initial weights (the optimizer state is not used by the comparison)
-        parity = parity_block(workload, model, imgs, labels, args.precision, light=light)
+        parity = parity_block(workload, model, imgs0, labels0, args.precision, light=light)
     eval_rec = None
-    if light:
+    if light if eval_forward is None else eval_forward:
         # evaluation forward (tc.py:4652-4812 / f3): eval mode, no autograd, forward-only workspace, same resident batch
         model.eval()
         with torch.no_grad():
             for _ in range(5):
-                ddp(imgs)
+                ddp(imgs0)
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
             te = time.perf_counter()
-            for _ in range(args.steps):
-                ddp(imgs)
+            for j in range(args.steps):
+                ddp(imgs[j % len(imgs)] if pooled else imgs0)
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -816,11 +964,19 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
                "config": {"workload": WORKLOAD_NAME[workload] + f", bs={batch}/GPU, 224^2, AdamW, random init"
                                       + (f", finetune mode {finetune_mode} (finetune.py:49-91)" if workload == "cls" else ""),
                           "global_batch": batch * world, "parallelism": f"dp{world}" + ("+forced world-1 RCCL all-reduces" if ddp.sync is not None and world == 1 else ""),
-                          "final_loss": round(loss_val, 5),
+                          "final_loss": round(loss_val, 5), "mean_loss": round(loss_mean, 5), "min_loss": round(loss_min, 5),
+                          "batches": (f"{N_IMG_BATCHES} resident image batches x {N_LABEL_SETS} Bernoulli(0.5) label vectors, a new pairing "
+                                      "every step" if pooled else "ONE resident batch (memorised: --single-batch A/B)"),
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "lr_schedule": ("per-iteration warm-up (engine_pretrain.py:47-48; 40 epochs x 390 it)" if workload == "mae"
                                           else "new lr every step" if args.lr_every_step else "constant")},
                "roofline": roof}
+        if degenerate:
+            rec["degenerate"] = f"cls loss fell to {loss_min:.2e} in the timed region: not a measurement of the training step"
+        if scale_info is not None:
+            rec["loss_scaling"] = scale_info
+        if sync_info is not None:
+            rec["grad_sync"] = sync_info
         if parity is not None:
             rec["parity"] = parity
         if busy is not None:
@@ -944,13 +1100,21 @@ def run_stub(args, world, rank):
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    # the self-verification keys of an N > 1 line, through the same dist_config() the GPU path uses
+    tw = time.perf_counter()
+    step()
+    sync_info = {"collectives_per_step": 1 if world > 1 else 0, "allreduce_bytes_per_step": 4 * x.numel() if world > 1 else 0,
+                 "largest_bucket_bytes": 4 * x.numel() if world > 1 else 0,
+                 "exposed_wait_ms": round((time.perf_counter() - tw) * 1e3, 4), "trainable_bytes": 4 * x.numel()}
+    dcfg = dist_config(world, rank, int(os.environ.get("LOCAL_RANK", "0")), "cpu", sync_info if rank == 0 else None,
+                       "gloo" if world > 1 else "none")
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": round(64 * world * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "stub step on the CPU (launch-path test, not a measurement)",
                           "config": {"workload": "stub", "global_batch": 64 * world, "parallelism": f"dp{world}",
-                                     "allreduce_check": float(y[0])}}))
+                                     "allreduce_check": float(y[0]), **dcfg}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -993,18 +1157,82 @@ def main():
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
     batch = args.batch or (64 if args.workload == "cls" else 256)
     head = run_workload(args, args.workload, batch, device, world, rank, True, finetune_mode=args.finetune_mode)
-    sub = None
-    if args.workload == "cls" and not args.no_mae and not args.batch and args.input == "resident":
-        # BASELINE.json metric: "(MAE pretrain + cls finetune)": configs[2], same process, same protocol
-        sub = run_workload(args, "mae", 256, device, world, rank, False)
+    default_line = args.workload == "cls" and not args.batch and args.input == "resident" and args.precision == "bf16"
+    subs = {}
+    if default_line and not args.no_fp16:
+        # the same fine-tune step in precision mode fp16: the 16-bit mode whose parity gate is SURVEY 8-d as written
+        subs["cls_fp16"] = run_workload(args, "cls", batch, device, world, rank, False, precision="fp16", kstats=False)
+    if default_line and not args.no_mae:
+        # BASELINE.json metric: "(MAE pretrain + cls finetune)" at bs=64/GPU; configs[2] / [3] run MAE at 256/GPU: both, same protocol
+        subs["mae_bs256"] = run_workload(args, "mae", 256, device, world, rank, False)
+        subs["mae_bs64"] = run_workload(args, "mae", 64, device, world, rank, False, kstats=False)
+        if not args.no_fp16:
+            subs["mae_bs256_fp16"] = run_workload(args, "mae", 256, device, world, rank, False, precision="fp16", kstats=False)
     c5 = None
-    if (args.workload == "cls" and args.finetune_mode == "full" and not args.no_c5 and not args.batch and args.input == "resident"
-            and args.graph != "on"):
+    if default_line and args.finetune_mode == "full" and not args.no_c5 and args.graph != "on":
         # configs[4] (C5): the staged fine-tune regimes of finetune.py:49-91 on the same synthetic step, + the eval forward
         c5 = {m: run_workload(args, "cls", batch, device, world, rank, False, finetune_mode=m, light=True)
               for m in ("none", "head+1", "head+2")}
 
     if rank == 0:
+        cfg = dict(head["config"])
+        roof = dict(head["roofline"])
+        # ---- flat scalars: the driver's record keeps the scalar members of `config`, `roofline` and `cpu_baseline` only ----
+        kern = roof.get("kernel")
+        if kern:
+            roof.update(kernel_name=kern["name"], kernel_class=kern["class"], kernel_launches_per_step=kern["launches"],
+                        kernel_avg_us=kern["avg_us"], kernel_tflops=kern["tflops"], kernel_frac=kern["frac"],
+                        kernel_share_of_gemm_time=kern["share_of_gemm_time"])
+            if "frac_on_held_cus" in kern:
+                roof.update(kernel_frac_on_held_cus=kern["frac_on_held_cus"], kernel_avg_cus_held=kern.get("avg_cus_held"))
+        traffic = roof.get("traffic")
+        if isinstance(traffic, dict):
+            roof["traffic_detail"] = traffic
+            roof["traffic"] = round(traffic["MB_per_launch"] * 1e6)           # HBM bytes per launch of the dominant kernel (PMC)
+            roof["traffic_algorithmic_bytes"] = round(traffic["algorithmic_MB_per_launch"] * 1e6)
+            roof["traffic_ratio"] = round(traffic["MB_per_launch"] / traffic["algorithmic_MB_per_launch"], 3)
+            roof["traffic_source"] = traffic["source"]
+        clk = held_clock()
+        if clk:
+            roof.update(held_clock_mhz=clk["mhz"], frac_of_peak_at_held_clock=round(roof["frac"] * 2400.0 / clk["mhz"], 4),
+                        held_clock_source=clk["source"])
+        if head.get("parity"):
+            par = head["parity"]
+            cfg.update(parity_pass=par["pass"], parity_logits_max_rel=par.get("logits_max_rel"), parity_loss_rel=par.get("loss_rel"),
+                       parity_weight_grad_rel_l2_worst=par.get("weight_grad_rel_l2_worst"),
+                       parity_fp32_mode_logits_max_rel=par.get("fp32_mode_logits_max_rel"))
+
+        def flat(prefix, r, parity_keys=()):
+            if r is None:
+                return
+            cfg[f"{prefix}_img_s"] = r["value"] if "degenerate" not in r else None
+            cfg[f"{prefix}_ms_per_step"] = r["ms_per_step"]
+            cfg[f"{prefix}_roofline_frac"] = r["roofline"]["frac"]
+            cfg[f"{prefix}_final_loss"] = r["config"]["final_loss"]
+            if "degenerate" in r:
+                cfg[f"{prefix}_degenerate"] = r["degenerate"]
+            if "loss_scaling" in r:
+                cfg[f"{prefix}_loss_scale"] = r["loss_scaling"]["loss_scale"]
+                cfg[f"{prefix}_skipped_steps_in_timed_region"] = r["loss_scaling"]["skipped_steps_in_timed_region"]
+            if r.get("parity"):
+                cfg[f"{prefix}_parity_pass"] = r["parity"]["pass"]
+                for k in parity_keys:
+                    if k in r["parity"]:
+                        cfg[f"{prefix}_parity_{k}"] = r["parity"][k]
+            if "eval_forward" in r:
+                cfg[f"{prefix}_eval_img_s"] = r["eval_forward"]["value"]
+
+        flat("cls_fp16", subs.get("cls_fp16"), ("logits_max_rel", "loss_rel", "weight_grad_rel_l2_worst", "vector_grad_rel_l2_worst"))
+        if subs.get("cls_fp16") and subs["cls_fp16"].get("parity"):
+            cfg["cls_fp16_parity_gates"] = "logits <= 2.0e-3 (fp16 operand-rounding floor 1.63e-3 + 25 %), loss <= 1e-3, every gradient <= 1e-2 rel-L2 (SURVEY 8-d)"
+        flat("mae_bs256", subs.get("mae_bs256"), ("loss_rel", "pred_rel_l2"))
+        flat("mae_bs64", subs.get("mae_bs64"), ("loss_rel", "pred_rel_l2"))
+        flat("mae_bs256_fp16", subs.get("mae_bs256_fp16"), ("loss_rel", "pred_rel_l2"))
+        for m, r in (c5 or {}).items():
+            flat("finetune_" + m.replace("+", "_plus_"), r, ("logits_max_rel",))
+        if head.get("grad_sync") or world > 1:
+            cfg.update(dist_config(world, rank, int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.get_device_name(device),
+                                   head.get("grad_sync"), dist.get_backend() if dist.is_initialized() else "none"))
         out = {
             "metric": "training-step images/sec/node, ViT-B/16 224^2 (" + ("cls fine-tune" if args.workload == "cls" else "MAE pre-train") + ")",
             "value": head["value"], "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1013,17 +1241,17 @@ def main():
             "data": "synthetic" if args.input == "resident" else
                     ("synthetic uint8 frames in pinned host memory (PCIe-inclusive)" +
                      (", 576x720, whole train transform on the device" if args.augment == "device" else "")),
-            "config": head["config"], "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"], "step_ms": head["step_ms"],
-            "preheat_steps": head["preheat_steps"],
-            "roofline": head["roofline"],
+            "config": cfg, "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"], "step_ms": head["step_ms"],
+            "preheat_steps": head["preheat_steps"], "timed_region_unix": head["timed_region_unix"],
+            "roofline": roof,
         }
-        if "parity" in head:
-            out["parity"] = head["parity"]
-        if "busy_host" in head:
-            out["busy_host"] = head["busy_host"]
-        if sub is not None:
-            out["mae"] = {"metric": "training-step images/sec/node, ViT-B/16 224^2 (MAE pre-train)", "steps": args.steps,
-                          "warmup": args.warmup, **sub}
+        for k in ("parity", "busy_host", "loss_scaling", "grad_sync"):
+            if k in head:
+                out[k] = head[k]
+        for name, r in subs.items():
+            out[name] = {"steps": args.steps, "warmup": args.warmup, **r}
+        if "mae_bs256" in subs:
+            out["mae"] = out["mae_bs256"]   # (the name rounds 1-3 used)
         if c5 is not None:
             out["finetune_modes"] = {m: {k: v for k, v in r.items() if k not in ("host_enqueue_ms_per_step", "preheat_steps")}
                                      for m, r in c5.items()}
@@ -1035,13 +1263,16 @@ def main():
             except Exception as e:  # context only: never fail the bench line over it
                 out["torch_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         print(json.dumps(out))
-        hard = [f"{name}: {k}" for name, rec in (("cls", out.get("parity")), ("mae", (out.get("mae") or {}).get("parity")))
-                if rec for k in rec.get("hard_fail", [])]
+        recs = [("cls", out.get("parity"))] + [(n, r.get("parity")) for n, r in subs.items()]
+        hard = [f"{name}: {k}" for name, rec in recs if rec for k in rec.get("hard_fail", [])]
         if hard:
             print("[bench] PARITY GATE FAILED: " + ", ".join(hard), file=sys.stderr, flush=True)
             if dist.is_initialized():
                 dist.destroy_process_group()
             sys.exit(4)
+    elif world > 1:
+        dist_config(world, rank, int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.get_device_name(device), None,
+                    dist.get_backend())  # (this rank's part of the all_gather_object behind rank 0's line)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -49,6 +49,15 @@ class GradSync:
         self._ranges: Dict[str, List[Tuple[int, int]]] = {"mat": [], "vec": []}
         self.launched: List[Tuple[str, int, int]] = []  # (region, lo, hi) of the last backward's collectives (tests / logs)
         self.plan_builds = 0
+        # "ready" events of blocks whose pieces were DEFERRED (bucket not full yet): the engine calls block_done(i) on the stream
+        # behind which block i's gradients are final -- the weight-gradient side stream, or the second one of a two-launch block,
+        # or the main stream for a frozen block -- and a later block_done may run on ANOTHER of those streams (the ungrouped tail
+        # block issues on `side`, block i+1's (proj, qkv) launch ran on `side2`).  The collective that finally carries a deferred
+        # piece is therefore ordered behind the event recorded when its block was reported, not just behind the issuing stream.
+        # (With the default 24-MiB bucket every ViT-B block flushes in its own call and nothing is ever deferred; any bucket_mb
+        # above one block's 28 MiB needs this.)
+        self._ready_events: List = []
+        self.waited_events = 0    # (tests: deferred ready-events a launch had to wait for)
 
     # ------------------------------------------------------------------------------------------
     @property
@@ -88,7 +97,28 @@ class GradSync:
         self._hi = f.G["mat"].numel()
         self._works = []
         self.launched = []
+        self._ready_events = []
         self._armed = True
+
+    def _record_ready(self):
+        """An event on the CURRENT stream (gradients of the block just reported are final behind it), or None on the CPU."""
+        if not self.rt.flat.G["mat"].is_cuda:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.rt.flat.G["mat"].device))
+        return ev
+
+    def _wait_ready(self):
+        """Order the current stream behind every block reported since the last launch (their pieces ride in this one)."""
+        cur = torch.cuda.current_stream(self.rt.flat.G["mat"].device) if self.rt.flat.G["mat"].is_cuda else None
+        for ev in self._ready_events:
+            if ev is not None:
+                if hasattr(ev, "wait_on"):
+                    ev.wait_on(cur)        # (test double)
+                else:
+                    cur.wait_event(ev)
+                self.waited_events += 1
+        self._ready_events = []
 
     def _launch(self, region: str, lo: int, hi: int):
         tensor = self.rt.flat.G[region][lo:hi]
@@ -122,6 +152,7 @@ class GradSync:
             self._hi = lo
             return
         if force or sum(b - a for a, b in pieces) >= self.bucket_elems:
+            self._wait_ready()
             for a, b in pieces:
                 self._launch("mat", a, b)
             self._hi = lo
@@ -131,6 +162,9 @@ class GradSync:
         if not self.active:
             return
         f = self.rt.flat
+        if not self._armed:
+            self._begin()
+        self._ready_events.append(self._record_ready())
         self._ready_down_to(f.offset[f.index[f"{prefix}{i}.attn.qkv.weight"]], force=False)
 
     def backward_done(self, in_backward: bool = True):

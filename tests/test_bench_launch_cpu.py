@@ -29,6 +29,13 @@ def test_self_launch_two_ranks_relays_rank0_line():
     assert rec["n_gpus"] == 2 and rec["steps"] == 5 and rec["warmup"] == 2 and rec["config"]["parallelism"] == "dp2"
     assert rec["config"]["allreduce_check"] == 3.0  # (rank 0: 1) + (rank 1: 2): both ranks were in the collective
     assert rec["value"] > 0 and rec["scaling"] == "weak"
+    # the self-verifying keys of an N > 1 line (main_pretrain.py:201-214 prints the same facts at start-up):
+    # built by bench.dist_config(), the function the GPU path calls, from torch.distributed itself and an all_gather_object
+    c = rec["config"]
+    assert c["world_size"] == 2 and c["backend"] == "gloo" and c["ranks_seen"] == 2
+    assert c["local_ranks"] == "0,1" and c["distinct_local_devices"] == 2 and c["devices"] == "0:cpu; 1:cpu"
+    assert c["sync_collectives_per_step"] == 1 and c["sync_allreduce_bytes_per_step"] == 4 * 4096
+    assert c["sync_exposed_wait_ms"] >= 0 and c["sync_trainable_bytes"] == 4 * 4096
 
 
 def test_single_rank_needs_no_launcher():

@@ -248,7 +248,7 @@ def test_registered_linear_bias_gelu_backward_runs_pm_dgelu(dt):
     gx, gW, gb = torch.autograd.grad(y, (x, W, b), dy)
     xr, Wr, br = x.detach().float().requires_grad_(True), W.detach().float().requires_grad_(True), b.detach().clone().requires_grad_(True)
     pre = F.linear(xr, Wr, br)
-    yr = F.gelu(pre.to(dt).float() + (pre - pre.detach()))  # gelu of the STORED pre-activation, gradient through pre
+    yr = F.gelu(pre.detach().to(dt).float() + (pre - pre.detach()))  # gelu of the STORED pre-activation, gradient through pre
     rx, rW, rb = torch.autograd.grad(yr, (xr, Wr, br), dy.float())
     tol = 2e-2 if dt == torch.bfloat16 else 3e-3
     assert rel(y.float(), yr) < tol and rel(gx.float(), rx) < tol and rel(gW, rW) < tol and rel(gb, rb) < tol

@@ -223,3 +223,61 @@ def test_sharded_evaluation_gloo():
         assert torch.equal(torch.from_numpy(rp), pr)
     # multi-class: softmax
     assert torch.allclose(T.class_probabilities(torch.tensor([[1.0, 2.0, 3.0]])).sum(), torch.tensor(1.0))
+
+
+def test_deferred_pieces_wait_for_the_stream_their_block_finished_on():
+    """ADVICE r3 (parallel.py): with a bucket larger than one block, block i's pieces are deferred and finally launched by a LATER
+    block_done -- which the engine may issue from a different stream (the ungrouped tail block reports on `side`, block i+1's
+    (proj, qkv) launch ran on `side2`).  GradSync records a ready-event per reported block and orders the launching stream behind
+    every event it has not consumed yet.  CPU rehearsal with event doubles: every launch must first wait for ALL blocks reported
+    since the previous launch, and a one-block bucket (nothing deferred) waits only for its own block."""
+    import ssl4polyp_amd as A
+    from ssl4polyp_amd.flat import FlatParams
+    from ssl4polyp_amd.parallel import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        m = A.ViT_from_MAE(None, True, 2, False, None, embed_dim=64, depth=4, num_heads=2, out_token="cls")
+        rt = m._rt
+        rt.flat = FlatParams(m, torch.bfloat16)
+        rt.flat.materialize(torch.device("cpu"))
+        log = []
+
+        class Ev:
+            def __init__(self, block, stream):
+                self.block, self.stream = block, stream
+
+            def wait_on(self, cur):
+                log.append(("wait", self.block, self.stream))
+
+        for bucket_mb, expect_deferred in ((64.0, True), (0.01, False)):
+            sync = GradSync(rt, None, bucket_mb=bucket_mb, force=True)
+            cur = {}
+            sync._record_ready = lambda: Ev(cur["block"], cur["stream"])
+            orig_launch = sync._launch
+            sync._launch = lambda r, lo, hi: (log.append(("launch", r, lo, hi)), orig_launch(r, lo, hi))[1]
+            log.clear()
+            # blocks 3, 2 report on "side2", the (ungrouped) tail blocks 1, 0 on "side" -- the engine's pattern
+            for i, st in ((3, "side2"), (2, "side2"), (1, "side"), (0, "side")):
+                cur.update(block=i, stream=st)
+                sync.block_done("blocks.", i)
+            sync.backward_done(in_backward=False)
+            sync.wait()
+            launches = [j for j, e in enumerate(log) if e[0] == "launch" and e[1] == "mat"]
+            assert launches, log
+            seen = set()
+            for j in launches:      # every mat launch is preceded (since the previous launch) by waits for the blocks it carries
+                k = j - 1
+                while k >= 0 and log[k][0] == "wait":
+                    seen.add(log[k][1])
+                    k -= 1
+            assert seen == {0, 1, 2, 3}, (bucket_mb, log)
+            first = launches[0]
+            waited_first = [e[1] for e in log[:first] if e[0] == "wait"]
+            if expect_deferred:     # one launch at the end carries everything: it waited for the side2 blocks too
+                assert sorted(waited_first) == [0, 1, 2, 3] and sync.waited_events == 4
+            else:                   # a bucket per block: the first launch waited for block 3 alone
+                assert waited_first == [3]
+    finally:
+        dist.destroy_process_group()
