@@ -611,6 +611,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   else static_assert(N == 0, "add the immediate");
 }
 
@@ -1222,8 +1225,11 @@ struct WgradGroupArgs {
 #endif
 };
 
-template <int BM_, int BN_, int WM, int WN, typename E = __bf16>
-__global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroupArgs g) {
+// NW = 8: the ping-pong loop (two waves per SIMD, 128 x 64 per wave).  NW = 4 (experiment, PM_GROUP_KERNEL=4): ONE wave per SIMD,
+// 128 x 128 per wave on the software-pipelined loop -- 16 fragment reads per 32 MFMAs instead of 12 per 16, i.e. 2/3 of the LDS
+// fragment traffic that co-limits the 8-wave loop here (both operands arrive by transpose reads), at 512 VGPRs per wave.
+template <int BM_, int BN_, int WM, int WN, typename E = __bf16, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void wgrad_group_kernel(WgradGroupArgs g) {
   // gridDim.x workgroups (a multiple of 8, or the whole work list) walk the (k-slice, tile) items t = blockIdx.x,
   // + gridDim.x, ...: the caller chooses how many CUs the weight-gradient stream takes from the dgrad chain beside it.
   // xcd_remap gives every XCD a contiguous run of items; within a k-slice consecutive items are neighbouring tiles
@@ -1256,7 +1262,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroupArgs g) {
 #endif
     // (the software-pipelined loop needs 254 VGPRs without the row sums: with them it spills 73 and runs 1.5x slower;
     //  without them, bias gradients by separate column-sum passes, it equals this loop with the row sums inside)
-    gemm_v3_tile<BM_, BN_, WM, WN, true, 4, true, true, true, 8, false, true, false, E>(a, tile - pr.tile_begin, slice);
+    if constexpr (NW == 8)
+      gemm_v3_tile<BM_, BN_, WM, WN, true, 4, true, true, true, 8, false, true, false, E>(a, tile - pr.tile_begin, slice);
+    else
+      gemm_v3_tile<BM_, BN_, WM, WN, true, 4, true, false, true, NW, true, true, false, E>(a, tile - pr.tile_begin, slice);
     __syncthreads();  // every wave is done with the LDS ring before the next tile's first stages are issued
   }
 }
@@ -1683,6 +1692,12 @@ int group_split_target() {
   return v;
 }
 
+// experiment hook, read once: PM_GROUP_KERNEL=4 -> the 4-wave (one wave per SIMD, 128 x 128 per wave) software-pipelined body
+int group_kernel_waves() {
+  static const int v = [] { const char* e = getenv("PM_GROUP_KERNEL"); return e && e[0] ? atoi(e) : 8; }();
+  return v;
+}
+
 // experiment hook, read once: PM_GROUP_FORCE_SPLIT=2|3 cuts the tiles of a LARGE group (ViT-B block: 108 tiles) into k-slices too,
 // so that a launch limited to fewer workgroups than tiles (max_blocks) walks equal shares (scratch/r3_exp17.sh)
 int group_force_split() {
@@ -1815,7 +1830,12 @@ extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_d
   }
   hipStream_t s = pm_stream(stream);
   PM_DISPATCH_16(in_dtype, E, {
-    if (bn == 256) {
+    if (bn == 256 && group_kernel_waves() == 4) {
+      auto kern = wgrad_group_kernel<256, 256, 2, 2, E, 4>;
+      constexpr int ring = 4 * (256 + 256) * 64;
+      PM_ALLOW_LDS(kern, ring);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ring, s, g);
+    } else if (bn == 256) {
       auto kern = wgrad_group_kernel<256, 256, 2, 4, E>;
       constexpr int ring = 4 * (256 + 256) * 64;
       PM_ALLOW_LDS(kern, ring);

@@ -55,6 +55,30 @@ def test_async_schedule_equals_serialised_runtime(tmp_path, workload, steps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workload,steps", [("cls", 4), ("mae", 3)])
+def test_auto_vmcnt_build_equals_shipped_library(tmp_path, workload, steps):
+    """The PM_LDS_IMAGE assumption as a gate (pm_common.h): the shipped k-loops read MFMA fragments with ds_read_b64_tr_b16 through a
+    `__restrict__` LDS pointer, which keeps this compiler from guarding each read with `s_waitcnt vmcnt(0)` while LDS-DMA loads are
+    in flight; the hand-placed counted waits + barriers are then the only synchronisation.  `-DPM_AUTO_VMCNT` (built by
+    __graft_entry__.build() into a side library) restores the compiler's guard -- slower, but correct whatever the waitcnt pass
+    does.  The same seeded ViT-B steps through both libraries must give the same bits; the compiler that built them is on record."""
+    import json
+    import __graft_entry__ as G
+    alt = G.alt_lib_path("autovmcnt")
+    assert os.path.exists(alt), f"{alt} missing: __graft_entry__.build() makes it"
+    info = json.load(open(G.BUILD_INFO))
+    assert "autovmcnt" in info["alt_libs"] and info["hipcc"] not in ("", "unknown"), info
+    here = G.hipcc_version()
+    if here != "unknown":
+        assert here == info["hipcc"], f"libraries built by `{info['hipcc']}`, this box has `{here}`: rebuild and re-run the gate"
+    a = _run(tmp_path, "shipped", workload, steps, {})
+    b = _run(tmp_path, "autovmcnt", workload, steps, {"POLYPMAE_LIB": alt})
+    assert a["losses"] == b["losses"]
+    for k in a["sd"]:
+        assert torch.equal(a["sd"][k], b["sd"][k]), k
+
+
+@pytest.mark.gpu
 def test_side_streams_are_shared_by_every_model_of_the_process():
     """One set of side streams per device (engine._shared_stream): the HIP runtime multiplexes streams onto a few hardware queues, and
     a set per model put a later model's weight-gradient stream onto the main stream's queue (the MAE step of the multi-model bench
