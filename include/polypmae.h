@@ -259,7 +259,11 @@ int pm_aug_color_jitter_u8(const unsigned char* src, unsigned char* dst, const p
 
 /* GaussianBlur: separable ksize-tap convolution with reflect padding in f32 (taps f32 [B][ksize], one row per sample: the
  * caller evaluates torchvision's _get_gaussian_kernel1d for its sigma), taps summed in index order with separate multiply and
- * add, rint + clamp back to u8.  tmp f32 [B][H][W][3].  ksize odd, ksize / 2 < min(H, W). */
+ * add, rint + clamp back to u8.  tmp f32 [B][H][W][3].  ksize odd, ksize / 2 < min(H, W).
+ * Exactness: bit for bit against oracle/augment_ref.py (two separable f32 passes in this summation order).  torchvision 0.10's
+ * tensor path builds the 2-D kernel (outer product of the 1-D taps) and runs ONE depthwise conv2d: different f32 rounding, so
+ * after rint a few pixels can differ from the reference transform by 1 grey level (the oracle agrees with a float64 2-D
+ * convolution to <= 1 level, > 99 % of pixels exactly); torchvision is absent here, so this stage is tolerance +-1 LSB, unpinned. */
 int pm_aug_gaussian_blur_u8(const unsigned char* src, float* tmp, unsigned char* dst, const float* taps, int ksize, int B, int H,
                             int W, void* stream);
 
@@ -322,7 +326,8 @@ int pm_vit_block_fwd(const pm_block_fwd_desc* d, void* stream);
  * sums of din (bias gradient of the Linear that produced the block input), NULL when there is none; accumulate bit j
  * (0 qkv, 1 proj, 2 fc1, 3 fc2): dW += instead of dW =.  ev_join (optional), ev_fork, ev_done are hipEvent_t of the caller:
  * ev_done fires when this block's matrix gradients are final and its operands may be overwritten.  The library creates,
- * keeps and frees nothing.  The weight-gradient group is validated (pm_wgrad_group_plan: shapes, alignment, workspace size)
+ * keeps and frees nothing.  The weight-gradient group is validated (pm_wgrad_group_plan: shapes, alignment; and a k-sliced
+ * group's ws_group_bytes against the plan's slab size -- too small is PM_EINVAL, not a silent fall-back to whole-K 256x128 tiles)
  * BEFORE the first launch: a refusal (PM_ESHAPE / PM_EALIGN / PM_EINVAL) returns with nothing enqueued on either stream, and
  * the caller falls back to per-kernel calls.  Any later non-zero status is a launch failure (PM_ELAUNCH). */
 typedef struct pm_block_bwd_desc {

@@ -136,6 +136,24 @@ __device__ __forceinline__ void store_tile_T(T* __restrict__ rowptr, bool valid,
 
 constexpr float kLog2e = 1.4426950408889634f;
 
+// Where Q / K / V rows of (batch b, head h) live inside the qkv buffer, in elements:
+//   base(which, b, h) = which * which_stride + b * batch_stride + h * head_stride, consecutive tokens `ld` apart.
+// token-major (timm's reshape of the qkv Linear's output, [B, N, 3, H, dh]): ld = 3 H dh, which = H dh, head = dh, batch = N ld.
+// head-major ([3, B, H, N, dh]: a head's rows contiguous, 25 KB at N = 197, dh = 64): ld = dh, which = B H N dh, head = N dh,
+// batch = H N dh -- what a qkv GEMM epilogue that scatters by head would write (experiment: PM_ATTN_HEADMAJOR=1 reads the
+// buffer that way; scratch/bench_attn_layout.py permutes the input accordingly).
+struct QkvLayout {
+  long ld, which_stride, head_stride, batch_stride;
+};
+inline QkvLayout qkv_layout(int B, int N, int H, int DH, bool head_major) {
+  if (head_major) return QkvLayout{(long)DH, (long)B * H * N * DH, (long)N * DH, (long)H * N * DH};
+  return QkvLayout{3L * H * DH, (long)H * DH, (long)DH, (long)N * 3L * H * DH};
+}
+inline bool attn_head_major() {
+  static const bool v = [] { const char* e = getenv("PM_ATTN_HEADMAJOR"); return e && e[0] == '1'; }();
+  return v;
+}
+
 // one wave per 32-row tile (7 waves for N = 197): every wave does identical work, nothing idles on a tail tile
 template <int NT> struct Waves { static constexpr int value = NT; };
 
@@ -398,7 +416,8 @@ template <int RB, typename T> __device__ __forceinline__ void dma_rows(char* img
 
 template <typename T, int DH, int NT>
 __global__ __launch_bounds__(NT * 64) void attn_fwd2_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                           float* __restrict__ lse, int N, int H, int BH, float scale) {
+                                                           float* __restrict__ lse, int N, int H, int BH, float scale,
+                                                           QkvLayout lay) {
   constexpr int RB = DH * 2;
   constexpr int IMG = NT * 32 * RB;  // bytes per image
   constexpr int PCS = IMG / 1024;    // DMA pieces per image
@@ -408,18 +427,18 @@ __global__ __launch_bounds__(NT * 64) void attn_fwd2_kernel(const T* __restrict_
   char* imgQ = smem + 4 * IMG;
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long ld = 3L * H * DH;
+  const long ld = lay.ld;
   const float c = scale * kLog2e;
   auto issue = [&](int head, int buf) {
     const int b = head / H, h = head % H;
-    const T* base = qkv + (long)b * N * ld + h * DH;
+    const T* base = qkv + (long)b * lay.batch_stride + (long)h * lay.head_stride;
     char* imgK = smem + buf * 2 * IMG;
 #pragma unroll
     for (int i = 0; i < (PCS + NT - 1) / NT; ++i) {
       const int p = wave + NT * i;
       if (p < PCS) {
-        dma_rows<RB>(imgK, base + H * DH, ld, N, p, lane);
-        dma_rows<RB>(imgK + IMG, base + 2 * H * DH, ld, N, p, lane);
+        dma_rows<RB>(imgK, base + lay.which_stride, ld, N, p, lane);
+        dma_rows<RB>(imgK + IMG, base + 2 * lay.which_stride, ld, N, p, lane);
         dma_rows<RB>(imgQ, base, ld, N, p, lane);
       }
     }
@@ -499,7 +518,8 @@ int launch_fwd2(const void* qkv, void* out, float* lse, int B, int N, int H, hip
   const float scale = 1.0f / sqrtf((float)DH);
   auto kern = attn_fwd2_kernel<T, DH, NT>;
   PM_ALLOW_LDS(kern, lds);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, s, (const T*)qkv, (T*)out, lse, N, H, BH, scale);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT * 64), lds, s, (const T*)qkv, (T*)out, lse, N, H, BH, scale,
+                     qkv_layout(B, N, H, DH, attn_head_major()));
   return pm_check_launch();
 }
 
@@ -530,7 +550,7 @@ template <typename T, int DH, int NT>
 __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                                 const T* __restrict__ dout,
                                                                 const float* __restrict__ lse, T* __restrict__ dqkv,
-                                                                int N, int H, float scale
+                                                                int N, int H, float scale, QkvLayout lay
 #ifdef PM_ATTN_DEBUG
                                                                 , int dbg  // diagnostic build: bit 0 skips pass 1, bit 1 pass 2
 #endif
@@ -554,16 +574,16 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const T* __rest
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const long ld = 3L * H * DH, ldo = (long)H * DH;
-  const T* base = qkv + (long)b * N * ld + h * DH;
+  const long ld = 3L * H * DH, ldo = (long)H * DH;   // (dqkv, out and dout stay token-major)
+  const T* base = qkv + (long)b * lay.batch_stride + (long)h * lay.head_stride;
   const T* dobase = dout + (long)b * N * ldo + h * DH;
 #pragma unroll
   for (int i = 0; i < (PCS + NT - 1) / NT; ++i) {
     const int p = wave + NT * i;
     if (p < PCS) {
-      dma_rows<RB>(imgQ, base, ld, N, p, lane);
-      dma_rows<RB>(imgK, base + H * DH, ld, N, p, lane);
-      dma_rows<RB>(imgV, base + 2 * H * DH, ld, N, p, lane);
+      dma_rows<RB>(imgQ, base, lay.ld, N, p, lane);
+      dma_rows<RB>(imgK, base + lay.which_stride, lay.ld, N, p, lane);
+      dma_rows<RB>(imgV, base + 2 * lay.which_stride, lay.ld, N, p, lane);
       dma_rows<RB>(imgDO, dobase, ldo, N, p, lane);
     }
   }
@@ -694,10 +714,10 @@ int launch_bwd_fused(const void* qkv, const void* out, const void* dout, const f
 #ifdef PM_ATTN_DEBUG
   static const int dbg = [] { const char* e = getenv("PM_ATTN_BWD_SKIP"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(NT * 64), lds, s, (const T*)qkv, (const T*)out, (const T*)dout, lse,
-                     (T*)dqkv, N, H, scale, dbg);
+                     (T*)dqkv, N, H, scale, qkv_layout(B, N, H, DH, attn_head_major()), dbg);
 #else
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(NT * 64), lds, s, (const T*)qkv, (const T*)out, (const T*)dout, lse,
-                     (T*)dqkv, N, H, scale);
+                     (T*)dqkv, N, H, scale, qkv_layout(B, N, H, DH, attn_head_major()));
 #endif
   return pm_check_launch();
 }

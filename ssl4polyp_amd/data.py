@@ -316,6 +316,11 @@ class DevicePrefetcher:
         """augment: a DeviceAugmenter -> the loader may yield decoded frames of any (batch-uniform) size and the WHOLE train
         transform of the reference (Resize, ColorJitter, GaussianBlur(25), flips, RandomRotation(180), ToTensor, Normalize) runs
         on the copy stream; `flip_p` is then ignored (the augmenter draws its own flips from `generator`).
+        LIMITATION: every frame of a batch must have the SAME decoded size (a batch is one [B, H, W, 3] array and the Resize taps
+        are cached per (H, W)); the reference resizes image by image, and Hyperkvasir / SUN mix several native resolutions.  A
+        loader over mixed-size data has to bucket frames by source size per batch (a batch sampler keyed on the manifest's size
+        column) -- or take the per-sample path that `pm_aug_resized_crop_u8` already has for the MAE transform.  The device path
+        is wired into bench.py and the tests; the cls training entry points still take whatever loader the caller passes.
         stream: where the copies and the transform run -- "own": a stream of the prefetcher (a fourth busy stream beside the
         engine's three: one hardware queue each, fastest on a single GPU); "side": the engine's weight-gradient stream (idle
         during the forward pass, when the next batch is staged) -- for data-parallel ranks, where RCCL's stream is the fourth busy

@@ -353,13 +353,16 @@ def evaluate_cls(model, loader: Iterable, device, max_batches: Optional[int] = N
         idx.append(it)
         sizes.append(lg.shape[0])
         lgs.append(lg)
-        tgs.append(torch.as_tensor(batch[1]).reshape(-1).to(torch.int64))
+        tg = torch.as_tensor(batch[1]).detach().cpu()   # targets stay on the host, in their own dtype and trailing shape
+        if tg.ndim == 0 or tg.shape[0] != lg.shape[0]:
+            raise ValueError(f"evaluate_cls: batch {it} has {lg.shape[0]} samples but targets of shape {tuple(tg.shape)}")
+        tgs.append(tg)
     n_class = lgs[0].shape[1] if lgs else 0
     if world > 1:
         # the bookkeeping (batch indices, sizes, host-side targets) is tiny and goes as one object gather; the logits travel
         # as ONE padded device collective (ranks may hold different row counts: ragged last batch, odd batch count)
         meta = [None] * world
-        dist.all_gather_object(meta, (idx, sizes, n_class, torch.cat(tgs) if tgs else torch.zeros(0, dtype=torch.int64)))
+        dist.all_gather_object(meta, (idx, sizes, n_class, tgs))   # (per-batch host tensors: sliced on dim 0 only, never flattened)
         n_class = max(m[2] for m in meta)
         rows = [sum(m[1]) for m in meta]
         pad = max(rows) if rows else 0
@@ -369,10 +372,11 @@ def evaluate_cls(model, loader: Iterable, device, max_batches: Optional[int] = N
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
         pieces = []  # (global batch index, logits rows on the device, targets)
-        for r, (r_idx, r_sizes, _, r_tg) in enumerate(meta):
+        for r, (r_idx, r_sizes, _, r_tgs) in enumerate(meta):
             o = 0
-            for b, n in zip(r_idx, r_sizes):
-                pieces.append((b, parts[r][o:o + n], r_tg[o:o + n]))
+            for b, n, tg in zip(r_idx, r_sizes, r_tgs):
+                assert tg.shape[0] == n, (r, b, n, tuple(tg.shape))
+                pieces.append((b, parts[r][o:o + n], tg))
                 o += n
         pieces.sort(key=lambda x: x[0])
         logits_dev = torch.cat([x[1] for x in pieces]) if pieces else mine[:0]
