@@ -41,7 +41,7 @@ FINETUNE_GFLOP = {"none": FWD_GFLOP_PER_IMG, "head+1": FWD_GFLOP_PER_IMG + 2 * B
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (same rate), f32 MFMA
 PEAK_HBM_GBPS = 8000.0                         # MI355X_MICROARCH.md: HBM3E
 # AdamW on the side stream beside the next forward: +0.5 % on the fine-tune step and +0.6 % on the MAE step under the final stream
-# layout (scratch/r3_exp31.sh; with a stream set per model and the update sharing a hardware queue it cost the MAE step 1.3 %);
+# layout (scratch/archive_r3/r3_exp31.sh; with a stream set per model and the update sharing a hardware queue it cost the MAE step 1.3 %);
 # PM_OVERLAP_ADAMW=0/1 forces either
 OVERLAP_ADAMW = {"cls": os.environ.get("PM_OVERLAP_ADAMW", "1") != "0", "mae": os.environ.get("PM_OVERLAP_ADAMW", "1") != "0"}
 MAE_IT_PER_EPOCH = 390  # ~100 k unlabelled frames / 256 per step
@@ -1141,7 +1141,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import ssl4polyp_amd
-    if os.environ.get("BENCH_LATE_STREAMS") != "1":  # (A/B switch of scratch/r3_exp20.sh)
+    if os.environ.get("BENCH_LATE_STREAMS") != "1":  # (A/B switch of scratch/archive_r3/r3_exp20.sh)
         ssl4polyp_amd.reserve_streams(device)  # before RCCL creates its streams: one hardware queue per engine stream
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1577,7 +1577,7 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
         // so it does for every dgrad (W read as stored by ds_read_b64_tr_b16) since those reads stopped waiting for the
         // whole DMA ring (PM_LDS_IMAGE): dfc1 66 -> 61 us, dqkv 51 -> 47, dfc2 101 -> 96, decoder dfc1 118 -> 107
         if ((epilogue == PM_EPI_RESIDUAL && !b_kmajor) || (b_kmajor && !dgrad_pp())) cfg = cfg == 10 ? 26 : 25;
-        // round 3 (scratch/r3_exp1.sh, r3_exp3.sh):
+        // round 3 (scratch/archive_r3/r3_exp1.sh, r3_exp3.sh):
         //  * the dGELU dgrad (reads the saved pre-activation, writes an act-typed [M, 4D] tensor) goes to the ping-pong loop
         //    with the LDS-staged epilogue: stand-alone 96.8 vs 95.1 us at ViT-B, 197 vs 220 us at the MAE decoder, and
         //    +0.6 % cls step rate in-step (whole 128-B row segments per store instead of 16-B pieces at a 6-KB stride)
@@ -1588,7 +1588,7 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
         //  * plain dgrads (dfc1 / dproj / dqkv: N = 768): 256-row tiles with the staged epilogue (cfg 24) although the 192-row
         //    direct kernel is faster ALONE (59-62 vs 65 us): in the step the chain runs beside the grouped weight gradients,
         //    which hold 108 CUs -- 150 tiles of 256 rows + 108 = the chip, 198 tiles of 192 rows + 108 oversubscribe it and the
-        //    chain's third of a round queues behind the long weight-gradient workgroups (scratch/r3_exp8.sh, r3_exp9.sh:
+        //    chain's third of a round queues behind the long weight-gradient workgroups (scratch/archive_r3/r3_exp8.sh, r3_exp9.sh:
         //    +1.0 % cls in four same-box pairs, MAE +0.2 %)
         if (epilogue == PM_EPI_DGELU && !dgrad_pp()) cfg = 8;
         else if (b_kmajor && !dgrad_pp()) cfg = 24;
@@ -1699,7 +1699,7 @@ int group_kernel_waves() {
 }
 
 // experiment hook, read once: PM_GROUP_FORCE_SPLIT=2|3 cuts the tiles of a LARGE group (ViT-B block: 108 tiles) into k-slices too,
-// so that a launch limited to fewer workgroups than tiles (max_blocks) walks equal shares (scratch/r3_exp17.sh)
+// so that a launch limited to fewer workgroups than tiles (max_blocks) walks equal shares (scratch/archive_r3/r3_exp17.sh)
 int group_force_split() {
   static const int v = [] { const char* e = getenv("PM_GROUP_FORCE_SPLIT"); return e && e[0] ? atoi(e) : 0; }();
   return v;

@@ -54,7 +54,7 @@ def _stream() -> int:
 _STREAMS: Dict[Tuple[int, str], "torch.cuda.Stream"] = {}
 # The second weight-gradient stream (busy in the backward only) IS the second forward chain's stream (busy in the forward only):
 # three engine streams + the main stream = four busy streams at most, one per hardware queue of the runtime's default, and one queue
-# left for RCCL in a data-parallel rank (scratch/r3_exp23.sh; PM_MERGE_AUX_SIDE2=0 gives the weight gradients a stream of their own)
+# left for RCCL in a data-parallel rank (scratch/archive_r3/r3_exp23.sh; PM_MERGE_AUX_SIDE2=0 gives the weight gradients a stream of their own)
 MERGE_AUX_SIDE2 = os.environ.get("PM_MERGE_AUX_SIDE2", "1") == "1"
 
 

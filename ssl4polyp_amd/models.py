@@ -685,12 +685,14 @@ def mae_vit_large_patch16_dec512d8b(**kwargs):
 
 
 def mae_vit_huge_patch14_dec512d8b(**kwargs):
-    """models_mae.py:239-244.  Not runnable on the HIP path: the row-in-registers LayerNorm kernels stop at D = 1024
-    (ViT-H is 1280) and a 14x14 patch gives a 588-element im2col row, which is not a multiple of the 16-byte chunks the
-    bf16 GEMM loads.  No shipped config of the reference uses it (run_hyperkvasir_pretraining.py:96 fixes
+    """models_mae.py:239-244.  Not runnable on the HIP path: ViT-H has 16 heads of 80 (the attention kernels tile dh = 32 / 64:
+    80 is neither a whole number of 32-wide output tiles nor a power-of-two LDS row), the row-in-registers LayerNorm kernels
+    stop at D = 1024 (ViT-H is 1280), and a 14x14 patch gives a 588-element im2col row, which is not a multiple of the 16-byte
+    chunks the 16-bit GEMM loads.  No shipped config of the reference uses it (run_hyperkvasir_pretraining.py:96 fixes
     mae_vit_base_patch16), so the factory fails at construction instead of at the first forward."""
-    raise NotImplementedError("mae_vit_huge_patch14 is outside the MI355X hot path (LayerNorm kernels: D <= 1024; "
-                              "patch 14 -> K = 588 is not 16-byte aligned in bf16); use the base or large factory")
+    raise NotImplementedError("mae_vit_huge_patch14 is outside the MI355X hot path (attention kernels: head dim 32 / 64, ViT-H "
+                              "has 80; LayerNorm kernels: D <= 1024; patch 14 -> K = 588 is not 16-byte aligned); use the base "
+                              "or large factory")
 
 
 mae_vit_base_patch16 = mae_vit_base_patch16_dec512d8b
