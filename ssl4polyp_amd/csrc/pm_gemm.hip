@@ -1507,6 +1507,14 @@ int tall_m() {  // tuning hook, read once: row count from which a problem counts
   static const int v = [] { const char* e = getenv("PM_TALL_M"); return e && e[0] ? atoi(e) : 20000; }();
   return v;
 }
+int few_tiles_threshold() {  // tuning hook, read once: PM_FEW_TILES=0 keeps every M >= 1024 problem on the ring kernel (round-3 dispatch)
+  static const int v = [] { const char* e = getenv("PM_FEW_TILES"); return e && e[0] ? atoi(e) : 128; }();
+  return v;
+}
+int few_tiles_max_m() {  // tuning hook, read once: largest M the few-tiles rule applies to
+  static const int v = [] { const char* e = getenv("PM_FEW_TILES_MAXM"); return e && e[0] ? atoi(e) : 4096; }();
+  return v;
+}
 bool dgrad_pp() {  // A/B switch, read once: dgrads on the ping-pong loop
   static const bool v = [] { const char* e = getenv("PM_DGRAD_PP"); return e && e[0] == '1'; }();
   return v;
@@ -1559,8 +1567,21 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
     PM_DISPATCH_ACT(in_dtype, T, return launch_generic<T>(a, a_kmajor, b_kmajor, s));
     return PM_EINVAL;
   }
+  // Few tiles (round 4, scratch/bench_gemm_smallm.py, profiles/r4_exp3_gemm_smallm*.txt): a problem with fewer than ~half as many
+  // 256 x 256 tiles as the chip has CUs runs ONE partial round of long workgroups on the ring kernel -- its time is a tile's
+  // latency whatever M is (proj at M = 1 600 ... 6 304: 25-28 us) -- while the 128 x 128 LDS-DMA kernel spreads the same work over
+  // 4x the workgroups, two per CU: M = 3 200 (MAE encoder at bs = 64/GPU) qkv 25.3 -> 21.2 us, proj 27.1 -> 18.7, fc2 57.4 -> 43.9,
+  // dfc1 55.0 -> 37.4, dqkv 43.3 -> 29.3; the half-batch forward chains of the fine-tune (M = 6 304) proj 28.1 -> 26.0, fc2 58.7 ->
+  // 54.0; the 512-wide MAE decoder at M = 12 608: dfc1 44.1 -> 38.5, dqkv 35.6 -> 30.7.  The crossover sits between 117 tiles
+  // (128 x 128 wins) and 150 (the ring wins) on all 56 measured (shape, epilogue) points: fewer than 128 tiles -> 128 x 128.
+  const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  // ... in the step the rule holds only where the WHOLE chain is small (experiment 4, profiles/r4_exp4_few_tiles.txt): sent to the
+  // 128 x 128 kernel, the half-batch proj / fc2 of the fine-tune forward (M = 6 304) cost the step 4 % (MAE bs = 256: 1.6 %) although
+  // they are faster alone -- two 66-KB workgroups on a CU keep the other chain's 128-KB ring workgroups off it -- while MAE at
+  // bs = 64/GPU gains 4.5-6 %.  Hence the cap on M.
+  const bool few_tiles = (force_cfg & 63) == 0 && tiles256 < few_tiles_threshold() && M <= few_tiles_max_m();
   // large-tile ring kernel: bf16, X k-normal (forward and dgrad GEMMs), big M
-  if (is16(in_dtype) && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (force_cfg & 63) != 1) {
+  if (is16(in_dtype) && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (force_cfg & 63) != 1 && !few_tiles) {
     // Tile / pipeline choice, tuned on the ViT-B/16 shapes at M = 12608 (scratch/bench_gemm6.py).
     // pm_debug_gemm_config(cfg) forces one of the variants below (0 = the heuristics).
     int cfg = force_cfg & 63;
