@@ -1400,6 +1400,9 @@ int launch_v3_cfg(int cfg, const GemmArgs& a, int b_kmajor, hipStream_t s) {
              return launch_v3<E, 256, 256, 2, 4, 4, 2, false, true>(a, b_kmajor, s);
     case 9: return launch_v3<E, 256, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);    // ping-pong, register epilogue
     case 10: return launch_v3<E, 192, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);   // 192-row tiles: finer M granularity
+    // 128-row tiles (experiment 6, round 4: the half-batch proj / fc2 of the forward chains hold 99 tiles of 192 rows on 256 CUs)
+    case 12: return launch_v3<E, 128, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);
+    case 13: return launch_v3<E, 128, 256, 2, 4, 4, 2, true, true>(a, b_kmajor, s);
     // software-pipelined loop (fragment reads and DMA issue between the wave's own MFMAs)
     case 24: return launch_v3<E, 256, 256, 2, 4, 4, 2, false, false, 8, true>(a, b_kmajor, s);
     case 25: return launch_v3<E, 256, 256, 2, 4, 4, 2, true, false, 8, true>(a, b_kmajor, s);

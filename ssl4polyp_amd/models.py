@@ -623,22 +623,24 @@ class MaskedAutoencoderViT(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
-    # pure data-movement helpers kept for API compatibility (models_mae.py:95-121)
+    # Pure data-movement helpers of the reference's public surface (models_mae.py:95-121: imgs [N, 3, H, W] <-> patches
+    # [N, L, p*p*3] with the channel fastest inside a patch).  Off the hot path -- the loss kernel fuses this layout
+    # (pm_mae_loss_fwd) -- and written as one view + permute each way; tests/test_oracle_golden.py pins the pixel order.
     def patchify(self, imgs):
         p = self.patch_embed.patch_size[0]
-        assert imgs.shape[2] == imgs.shape[3] and imgs.shape[2] % p == 0
-        h = w = imgs.shape[2] // p
-        x = imgs.reshape(shape=(imgs.shape[0], 3, h, p, w, p))
-        x = torch.einsum("nchpwq->nhwpqc", x)
-        return x.reshape(shape=(imgs.shape[0], h * w, p ** 2 * 3))
+        n, c, hh, ww = imgs.shape
+        if hh != ww or hh % p or c != 3:
+            raise ValueError(f"patchify expects square 3-channel images whose side is a multiple of {p} (got {tuple(imgs.shape)})")
+        g = hh // p
+        return imgs.view(n, c, g, p, g, p).permute(0, 2, 4, 3, 5, 1).reshape(n, g * g, p * p * c)
 
     def unpatchify(self, x):
         p = self.patch_embed.patch_size[0]
-        h = w = int(x.shape[1] ** 0.5)
-        assert h * w == x.shape[1]
-        x = x.reshape(shape=(x.shape[0], h, w, p, p, 3))
-        x = torch.einsum("nhwpqc->nchpwq", x)
-        return x.reshape(shape=(x.shape[0], 3, h * p, h * p))
+        n, L, _ = x.shape
+        g = math.isqrt(L)
+        if g * g != L:
+            raise ValueError(f"unpatchify expects a square number of patches (got {L})")
+        return x.view(n, g, g, p, p, 3).permute(0, 5, 1, 3, 2, 4).reshape(n, 3, g * p, g * p)
 
     def _draw_noise(self, B: int, device) -> torch.Tensor:
         """The masking noise of models_mae.py:132 (`torch.rand(N, L, device=x.device)`) from the library's counter-based generator

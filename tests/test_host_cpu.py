@@ -171,3 +171,17 @@ def test_philox_restatement_against_random123_known_answers():
     x = mae_noise(1000, 1234, 7)
     assert x.dtype.name == "float32" and x.min() >= 0.0 and x.max() < 1.0 and abs(x.mean() - 0.5) < 0.05
     assert not (mae_noise(1000, 1234, 8) == x).all() and (mae_noise(997, 1234, 7) == x[:997]).all()
+
+
+def test_module_patchify_helpers_match_the_reference_fixture(golden):
+    """MaskedAutoencoderViT.patchify / unpatchify (models_mae.py:95-121; pure data movement, off the hot path, CPU-capable) against
+    the reference-generated index-ramp fixture that pins the pixel order."""
+    import numpy as np
+    import torch
+    import ssl4polyp_amd as A
+    fx = golden("tables.npz")
+    m = A.MaskedAutoencoderViT(img_size=32, patch_size=8, embed_dim=64, depth=1, num_heads=2, decoder_embed_dim=32, decoder_depth=1,
+                               decoder_num_heads=1)
+    ramp = torch.arange(2 * 3 * 32 * 32, dtype=torch.float32).reshape(2, 3, 32, 32)
+    np.testing.assert_array_equal(m.patchify(ramp).numpy(), fx["patchify_ramp"])
+    np.testing.assert_array_equal(m.unpatchify(torch.from_numpy(fx["patchify_ramp"])).numpy(), fx["unpatchify_ramp"])
