@@ -625,7 +625,7 @@ class MaskedAutoencoderViT(nn.Module):
 
     # Pure data-movement helpers of the reference's public surface (models_mae.py:95-121: imgs [N, 3, H, W] <-> patches
     # [N, L, p*p*3] with the channel fastest inside a patch).  Off the hot path -- the loss kernel fuses this layout
-    # (pm_mae_loss_fwd) -- and written as one view + permute each way; tests/test_oracle_golden.py pins the pixel order.
+    # (pm_mae_loss_fwd) -- and written as one view + permute each way; the reference-made ramp fixture pins the pixel order.
     def patchify(self, imgs):
         p = self.patch_embed.patch_size[0]
         n, c, hh, ww = imgs.shape
