@@ -1078,6 +1078,8 @@ def run_stub(args, world, rank):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
         dist.init_process_group("gloo")
+    if os.environ.get("BENCH_STUB_NOISE") == "1":  # a library banner on file descriptor 1 (what RCCL does at communicator start-up)
+        os.write(1, b"RCCL version : stub banner on fd 1\nHostname     : stub\n")
     x = torch.ones(1 << 12)
 
     def step():
@@ -1109,7 +1111,7 @@ def run_stub(args, world, rank):
     dcfg = dist_config(world, rank, int(os.environ.get("LOCAL_RANK", "0")), "cpu", sync_info if rank == 0 else None,
                        "gloo" if world > 1 else "none")
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": round(64 * world * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
+        emit(json.dumps({"metric": "stub", "value": round(64 * world * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "stub step on the CPU (launch-path test, not a measurement)",
@@ -1119,10 +1121,30 @@ def run_stub(args, world, rank):
         dist.destroy_process_group()
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL prints a five-line version banner on fd 1 when its
+    first communicator comes up (seen under --force-sync: "RCCL version : ... Librccl path : ..."), gloo and the HIP runtime have their
+    own -- so from here on file descriptor 1 IS stderr for everything in this process, and only emit() writes to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line: str):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus))  # before anything touches the GPU in this process
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1262,7 +1284,7 @@ def main():
                 out["torch_baseline"] = torch_baseline(device, 64)
             except Exception as e:  # context only: never fail the bench line over it
                 out["torch_baseline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
-        print(json.dumps(out))
+        emit(json.dumps(out))
         recs = [("cls", out.get("parity"))] + [(n, r.get("parity")) for n, r in subs.items()]
         hard = [f"{name}: {k}" for name, rec in recs if rec for k in rec.get("hard_fail", [])]
         if hard:

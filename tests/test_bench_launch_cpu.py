@@ -44,6 +44,16 @@ def test_single_rank_needs_no_launcher():
     assert json.loads(p.stdout.strip())["n_gpus"] == 1
 
 
+def test_library_banners_on_fd1_do_not_reach_stdout():
+    """RCCL prints a version banner on file descriptor 1 when its communicator comes up (seen on the GPU box under --force-sync);
+    bench.py hands fd 1 to stderr at start-up and writes its one JSON line to the saved descriptor: stdout stays ONE line."""
+    p, _ = _run({"BENCH_STUB_NOISE": "1"}, "--gpus", "1", "--steps", "3", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1, p.stdout
+    assert "stub banner on fd 1" in p.stderr
+
+
 def test_a_dead_rank_fails_the_job_and_frees_the_others():
     # rank 1 exits before the rendezvous; rank 0 would wait in init_process_group for its peer (default timeout: minutes)
     p, dt = _run({"BENCH_STUB_FAIL_RANK": "1"}, "--gpus", "2", "--steps", "3", "--warmup", "1", timeout=120)
