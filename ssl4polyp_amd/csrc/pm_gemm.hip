@@ -1220,23 +1220,17 @@ struct WgradGroupArgs {
   int ksteps_split;
   int auto_order;     // per-problem tile order: the shorter side fastest (0: row by row, the A/B baseline)
   long total_vec, bias_begin, bias_total;  // reduce launch: float4 items, then bias rows
+  int xcds;           // XCDs the work is confined to (8: all).  < 8: the grid is 8 / xcds times the work and the workgroups the
+                      // hardware deals to the other XCDs (workgroup id % 8 >= xcds) leave at once -- see pm_wgrad_group
 #ifdef PM_GEMM_STAMP
   unsigned long long* stamps;
 #endif
 };
 
-// NW = 8: the ping-pong loop (two waves per SIMD, 128 x 64 per wave).  NW = 4 (experiment, PM_GROUP_KERNEL=4): ONE wave per SIMD,
-// 128 x 128 per wave on the software-pipelined loop -- 16 fragment reads per 32 MFMAs instead of 12 per 16, i.e. 2/3 of the LDS
-// fragment traffic that co-limits the 8-wave loop here (both operands arrive by transpose reads), at 512 VGPRs per wave.
-template <int BM_, int BN_, int WM, int WN, typename E = __bf16, int NW = 8>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void wgrad_group_kernel(WgradGroupArgs g) {
-  // gridDim.x workgroups (a multiple of 8, or the whole work list) walk the (k-slice, tile) items t = blockIdx.x,
-  // + gridDim.x, ...: the caller chooses how many CUs the weight-gradient stream takes from the dgrad chain beside it.
-  // xcd_remap gives every XCD a contiguous run of items; within a k-slice consecutive items are neighbouring tiles
-  // (same dY panel -> same private L2); with gridDim.x % 8 == 0 a workgroup stays on its XCD's run.
-  const int work = g.total_tiles * g.split;
-  for (int t = blockIdx.x; t < work; t += gridDim.x) {
-    const int w = xcd_remap(t, work);
+// one (k-slice, tile) work item of a grouped launch
+template <int BM_, int BN_, int WM, int WN, typename E, int NW>
+__device__ __forceinline__ void group_item(const WgradGroupArgs& g, const int w) {
+  {
     const int slice = w / g.total_tiles, tile = w - slice * g.total_tiles;
     int pi = 0;
 #pragma unroll
@@ -1267,6 +1261,34 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void wgrad_group_kernel(W
     else
       gemm_v3_tile<BM_, BN_, WM, WN, true, 4, true, false, true, NW, true, true, false, E>(a, tile - pr.tile_begin, slice);
     __syncthreads();  // every wave is done with the LDS ring before the next tile's first stages are issued
+  }
+}
+
+// NW = 8: the ping-pong loop (two waves per SIMD, 128 x 64 per wave).  NW = 4 (experiment, PM_GROUP_KERNEL=4): ONE wave per SIMD,
+// 128 x 128 per wave on the software-pipelined loop -- 16 fragment reads per 32 MFMAs instead of 12 per 16, i.e. 2/3 of the LDS
+// fragment traffic that co-limits the 8-wave loop here (both operands arrive by transpose reads), at 512 VGPRs per wave.
+template <int BM_, int BN_, int WM, int WN, typename E = __bf16, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void wgrad_group_kernel(WgradGroupArgs g) {
+  // gridDim.x workgroups (a multiple of 8, or the whole work list) walk the (k-slice, tile) items t = blockIdx.x,
+  // + gridDim.x, ...: the caller chooses how many CUs the weight-gradient stream takes from the dgrad chain beside it.
+  // xcd_remap gives every XCD a contiguous run of items; within a k-slice consecutive items are neighbouring tiles
+  // (same dY panel -> same private L2); with gridDim.x % 8 == 0 a workgroup stays on its XCD's run.
+  const int work = g.total_tiles * g.split;
+  if (g.xcds < 8) {
+    // few tiles (the (proj, qkv) launch of a ViT-B block: 36): confined to g.xcds of the 8 XCDs, every XCD's run of consecutive
+    // tiles is 8 / xcds times longer, i.e. shares more dY / X panels in ONE L2 instead of fetching them into several
+    const int xcd = blockIdx.x & 7;
+    if (xcd >= g.xcds) return;
+    const int t = (blockIdx.x >> 3) * g.xcds + xcd;   // one work item per participating workgroup (grid sized for it)
+    if (t >= work) return;
+    const int q = work / g.xcds, r = work % g.xcds;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t / g.xcds);
+    group_item<BM_, BN_, WM, WN, E, NW>(g, w);
+    return;
+  }
+  for (int t = blockIdx.x; t < work; t += gridDim.x) {
+    const int w = xcd_remap(t, work);
+    group_item<BM_, BN_, WM, WN, E, NW>(g, w);   // (ends in a block barrier: the LDS ring is free for the next item)
   }
 }
 
@@ -1716,6 +1738,16 @@ int group_split_target() {
   return v;
 }
 
+// tuning hooks, read once: a whole-K group of at most PM_GROUP_CONFINE_WORK tiles (default 0 = off) runs on PM_GROUP_CONFINE_XCDS XCDs
+int group_confine_xcds() {
+  static const int v = [] { const char* e = getenv("PM_GROUP_CONFINE_XCDS"); const int x = e && e[0] ? atoi(e) : 4; return x < 1 ? 1 : (x > 8 ? 8 : x); }();
+  return v;
+}
+int group_confine_max_work() {
+  static const int v = [] { const char* e = getenv("PM_GROUP_CONFINE_WORK"); return e && e[0] ? atoi(e) : 0; }();
+  return v;
+}
+
 // experiment hook, read once: PM_GROUP_KERNEL=4 -> the 4-wave (one wave per SIMD, 128 x 128 per wave) software-pipelined body
 int group_kernel_waves() {
   static const int v = [] { const char* e = getenv("PM_GROUP_KERNEL"); return e && e[0] ? atoi(e) : 8; }();
@@ -1847,10 +1879,18 @@ extern "C" int pm_wgrad_group(const pm_wgrad_item* items, int n, int K, int in_d
       if (items[i].dbias) g.bias_total += items[i].n_out;
   const int work = total * pl.split;
   int grid = work;
+  g.xcds = 8;
   if (max_blocks > 0 && max_blocks < work) {
     grid = (max_blocks / 8) * 8;  // whole XCD rounds: a workgroup keeps walking its own XCD's run of items
     if (grid < 8) grid = 8;
     if (grid > work) grid = work;
+  } else if (pl.split == 1 && work <= group_confine_max_work() && group_confine_xcds() < 8) {
+    // A small whole-K group (the (proj, qkv) launch of a ViT-B block: 36 tiles) on all 8 XCDs gives each L2 a run of 4-5 tiles:
+    // few tiles share a dY / X panel in one L2, the panels are fetched by several (PMC: 258.8 MB against 125.7 MB algorithmic).
+    // Confined to 4 XCDs the runs are 9 tiles long.  The hardware deals workgroups to the XCDs round-robin by id, so the grid is
+    // 8 / xcds times the work and the workgroups that land on the other XCDs return at once.
+    g.xcds = group_confine_xcds();
+    grid = (work + g.xcds - 1) / g.xcds * 8;
   }
   hipStream_t s = pm_stream(stream);
   PM_DISPATCH_16(in_dtype, E, {
