@@ -219,7 +219,7 @@ def kernel_stats(model, step):
     k.BLOCK_CALLS = False  # the instrumented steps issue every forward kernel as its own call (same launches), so the hooks see them
     orig = dict(gemm=k.gemm, lnf=k.layernorm_fwd, lnb=k.layernorm_bwd, af=k.attention_fwd, ab=k.attention_bwd, wg=k.wgrad_group)
     rec, hbm, att = [], [], []
-    act_b = 2 if k.precision == "bf16" else 4
+    act_b = 4 if k.precision == "fp32" else 2
 
     def ev2():
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

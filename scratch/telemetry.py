@@ -60,10 +60,16 @@ def main():
             return float("nan")
         return float(v.value)
 
+    def membusy(d):
+        v = ctypes.c_uint32(0)
+        if lib.rsmi_dev_memory_busy_percent_get(ctypes.c_uint32(d), ctypes.byref(v)) != 0:
+            return float("nan")
+        return float(v.value)
+
     caps = [u64(lib.rsmi_dev_power_cap_get, d, ctypes.c_uint32(0)) / 1e6 for d in range(ndev)]
     with open(a.out, "w") as fh:
         fh.write("# power caps (W) per device: " + ",".join(f"{c:.0f}" for c in caps) + "\n")
-        fh.write("t_unix,dev,sclk_mhz,mclk_mhz,power_w,temp_junction_c,busy_pct\n")
+        fh.write("t_unix,dev,sclk_mhz,mclk_mhz,power_w,temp_junction_c,busy_pct,mem_busy_pct\n")
         t_end = time.time() + a.seconds
         period = 1.0 / a.hz
         nxt = time.time()
@@ -74,7 +80,7 @@ def main():
                 if p != p:
                     p = u64(lib.rsmi_dev_power_ave_get, d, ctypes.c_uint32(0))
                 tj = i64(lib.rsmi_dev_temp_metric_get, d, ctypes.c_uint32(1), ctypes.c_int(0)) / 1e3  # junction, current
-                fh.write(f"{t:.4f},{d},{clk(d, 0):.0f},{clk(d, 4):.0f},{p / 1e6:.1f},{tj:.1f},{busy(d):.0f}\n")
+                fh.write(f"{t:.4f},{d},{clk(d, 0):.0f},{clk(d, 4):.0f},{p / 1e6:.1f},{tj:.1f},{busy(d):.0f},{membusy(d):.0f}\n")
             fh.flush()
             nxt += period
             dt = nxt - time.time()
