@@ -539,18 +539,22 @@ def find_existing_checkpoint(stem_path):
 
 
 def save_cls_checkpoint(path, epoch: int, model, optimizer, scheduler=None, loss: Optional[float] = None,
-                        extra: Optional[dict] = None, pointer=None, writer: Optional[AsyncCheckpointWriter] = None) -> Path:
+                        extra: Optional[dict] = None, pointer=None, writer: Optional[AsyncCheckpointWriter] = None,
+                        loss_scaler=None) -> Path:
     """tc.py:7036-7111 payload: epoch / model_state_dict / optimizer_state_dict / scaler_state_dict / loss /
     py_state / np_state / torch_state (+ scheduler_state_dict only when a scheduler exists, tc.py:7065-7066); `extra`
     carries the reference's val_* / monitor_* / threshold fields unchanged.  `pointer`: the `<stem>.pth` link to move
-    onto this file (tc.py:7111)."""
+    onto this file (tc.py:7111).  `loss_scaler`: the optim.LossScaler (or torch GradScaler) of a precision-mode-fp16 run; its state
+    goes where the reference puts `scaler.state_dict()` (tc.py:7049)."""
     import random
 
     import numpy as np
     path = Path(path)
     if _is_main():
+        scaler_sd = loss_scaler.state_dict() if loss_scaler is not None else None
         payload = {"epoch": epoch, "model_state_dict": _host_state_dict(model),
-                   "optimizer_state_dict": _host_optimizer_state(optimizer), "scaler_state_dict": grad_scaler_state(), "loss": loss,
+                   "optimizer_state_dict": _host_optimizer_state(optimizer), "scaler_state_dict": scaler_sd or grad_scaler_state(),
+                   "loss": loss,
                    "py_state": random.getstate(), "np_state": np.random.get_state(), "torch_state": torch.get_rng_state()}
         if scheduler is not None:
             payload["scheduler_state_dict"] = scheduler.state_dict()
@@ -571,7 +575,7 @@ class ClsResume:
 
 
 def load_cls_checkpoint(stem_path, model, optimizer=None, scheduler=None, parent_checkpoint=None,
-                        restore_rng: bool = True) -> ClsResume:
+                        restore_rng: bool = True, loss_scaler=None) -> ClsResume:
     """tc.py:5667-5714 + 5976-5980: resume from `<stem>.pth` / the newest `<stem>_e*_*.pth` (model, optimizer, scheduler,
     Python / NumPy / torch RNG streams, monitor value, thresholds; repairs a missing pointer), else start from a parent
     run's weights (`parent_checkpoint`: payload with model_state_dict or a bare state dict), else a fresh start."""
@@ -607,6 +611,8 @@ def load_cls_checkpoint(stem_path, model, optimizer=None, scheduler=None, parent
                 optimizer.load_state_dict(main["optimizer_state_dict"])
             if scheduler is not None and "scheduler_state_dict" in main:
                 scheduler.load_state_dict(main["scheduler_state_dict"])
+            if loss_scaler is not None and main.get("scaler_state_dict"):  # tc.py:5978
+                loss_scaler.load_state_dict(main["scaler_state_dict"])
         return info
     if parent_checkpoint:
         parent = Path(parent_checkpoint).expanduser()
