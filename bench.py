@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity block (CPU time)")
     ap.add_argument("--no-mae", action="store_true", help="cls headline only (no MAE sub-records)")
     ap.add_argument("--no-fp16", action="store_true", help="skip the precision-mode fp16 sub-records (cls bs=64, MAE bs=256)")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the short fp32-mode (exact-f32 MFMA) cls record")
     ap.add_argument("--single-batch", action="store_true",
                     help="A/B switch: train on ONE resident batch with fixed labels, as rounds 1-3 did (the fine-tune memorises it: "
                          "loss -> 1e-5, all-zero dlogits in the linear-probe regimes); default: 8 resident image batches x 64 label "
@@ -1184,6 +1185,13 @@ def main():
     if default_line and not args.no_fp16:
         # the same fine-tune step in precision mode fp16: the 16-bit mode whose parity gate is SURVEY 8-d as written
         subs["cls_fp16"] = run_workload(args, "cls", batch, device, world, rank, False, precision="fp16", kstats=False)
+    if default_line and not args.no_fp32:
+        # the mode that meets the north-star's 1e-3 on the LOGITS too (exact-f32 MFMA, 1/16 of the 16-bit rate): a short record, so that
+        # the line carries a throughput for every parity level -- fp32 (logits 5e-6), fp16 (SURVEY 8-d as written; logits at the fp16
+        # operand-rounding floor), bf16 (headline)
+        a32 = argparse.Namespace(**{**vars(args), "steps": min(args.steps, 10), "warmup": min(args.warmup, 2), "preheat": 0.3,
+                                    "no_parity": True})
+        subs["cls_fp32"] = run_workload(a32, "cls", batch, device, world, rank, False, precision="fp32", kstats=False)
     if default_line and not args.no_mae:
         # BASELINE.json metric: "(MAE pretrain + cls finetune)" at bs=64/GPU; configs[2] / [3] run MAE at 256/GPU: both, same protocol
         subs["mae_bs256"] = run_workload(args, "mae", 256, device, world, rank, False)
@@ -1247,6 +1255,9 @@ def main():
         flat("cls_fp16", subs.get("cls_fp16"), ("logits_max_rel", "loss_rel", "weight_grad_rel_l2_worst", "vector_grad_rel_l2_worst"))
         if subs.get("cls_fp16") and subs["cls_fp16"].get("parity"):
             cfg["cls_fp16_parity_gates"] = "logits <= 2.0e-3 (fp16 operand-rounding floor 1.63e-3 + 25 %), loss <= 1e-3, every gradient <= 1e-2 rel-L2 (SURVEY 8-d)"
+        flat("cls_fp32", subs.get("cls_fp32"))
+        if subs.get("cls_fp32") and head.get("parity"):
+            cfg["cls_fp32_parity_logits_max_rel"] = head["parity"].get("fp32_mode_logits_max_rel")   # (measured in the headline's parity block)
         flat("mae_bs256", subs.get("mae_bs256"), ("loss_rel", "pred_rel_l2"))
         flat("mae_bs64", subs.get("mae_bs64"), ("loss_rel", "pred_rel_l2"))
         flat("mae_bs256_fp16", subs.get("mae_bs256_fp16"), ("loss_rel", "pred_rel_l2"))
@@ -1271,7 +1282,7 @@ def main():
             if k in head:
                 out[k] = head[k]
         for name, r in subs.items():
-            out[name] = {"steps": args.steps, "warmup": args.warmup, **r}
+            out[name] = {"steps": args.steps if name != "cls_fp32" else min(args.steps, 10), "warmup": args.warmup, **r}
         if "mae_bs256" in subs:
             out["mae"] = out["mae_bs256"]   # (the name rounds 1-3 used)
         if c5 is not None:

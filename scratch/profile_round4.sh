@@ -5,7 +5,7 @@
 # (gpurun merges at most 64 MiB back).
 TAG=$1; NAME=$2; shift; shift
 REPO=$PWD; OUT=$REPO/gpurun_out/prof_$TAG; mkdir -p $OUT $REPO/gpurun_out/profiles_r4
-B="--no-cpu-baseline --no-parity --no-torch-baseline --no-mae --no-c5 --no-fp16 --preheat 0.3"
+B="--no-cpu-baseline --no-parity --no-torch-baseline --no-mae --no-c5 --no-fp16 --no-fp32 --preheat 0.3"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $REPO/bench.py --steps 10 --warmup 3 $B "$@" > $OUT/stats.log 2>&1
 grep "^{\"metric\"" $OUT/stats.log > $OUT/bench.json

@@ -260,3 +260,51 @@ def test_registered_linear_bias_gelu_backward_runs_pm_dgelu(dt):
     p32 = p.float().requires_grad_(True)
     F.gelu(p32).backward(a.float())
     assert rel(out.float(), p32.grad) < (1e-2 if dt == torch.bfloat16 else 1.5e-3)
+
+
+def test_fp16_training_loops_checkpoint_the_loss_scaler(tmp_path):
+    """train_one_epoch_mae / train_epoch_cls with `loss_scaler=` (engine_pretrain.py:65-72, tc.py:4533-4546): losses go down, the
+    logged gradient statistics are those of the UNSCALED gradients, and both checkpoint formats carry the scaler's state
+    (misc.py:311-318 `scaler`, tc.py:7049 `scaler_state_dict`) and restore it."""
+    from types import SimpleNamespace
+    import numpy as np
+    import ssl4polyp_amd as A
+    from ssl4polyp_amd import train as T
+    from ssl4polyp_amd.optim import FusedAdamW, LossScaler, add_weight_decay
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(21)
+    m = A.MaskedAutoencoderViT(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2, decoder_embed_dim=32, decoder_depth=1,
+                               decoder_num_heads=1, precision="fp16").to(dev)
+    opt = FusedAdamW(m, add_weight_decay(m, 0.05), lr=2e-3, betas=(0.9, 0.95))
+    sc = LossScaler(init_scale=1024.0, growth_interval=5)
+    args = SimpleNamespace(lr=2e-3, min_lr=0.0, warmup_epochs=1, epochs=4, accum_iter=2, mask_ratio=0.75)
+    loader = T.SyntheticLoader(8, 12, dev, img_size=32, seed=3)
+    s0 = T.train_one_epoch_mae(m, loader, opt, dev, 0, args, log_every=3, printer=None, loss_scaler=sc)
+    s1 = T.train_one_epoch_mae(m, loader, opt, dev, 1, args, log_every=3, printer=None, loss_scaler=sc)
+    assert np.isfinite(s0.loss) and s1.loss < s0.loss and s1.grad_nan == 0 and s1.grad_inf == 0
+    # 12 optimizer steps (24 micro-batches, accum 2), growth every 5 clean ones: 1024 -> 4096; the logged norm is unscaled
+    assert sc.counters() == {"steps": 12, "skipped": 0, "found_inf_last": False} and sc.get_scale() == 4096.0
+    assert 0 < s1.history[-1]["grad_norm"] < 100
+    ck = T.save_mae_checkpoint(tmp_path, 1, m, opt, args, scaler_state=sc.state_dict())
+    sc2 = LossScaler()
+    m2 = A.MaskedAutoencoderViT(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2, decoder_embed_dim=32, decoder_depth=1,
+                                decoder_num_heads=1, precision="fp16").to(dev)
+    m2._rt.ensure(dev)
+    opt2 = FusedAdamW(m2, add_weight_decay(m2, 0.05), lr=2e-3, betas=(0.9, 0.95))
+    assert T.load_mae_checkpoint(ck, m2, opt2, args, loss_scaler=sc2) == 2
+    assert sc2.get_scale() == 4096.0 and sc2.state_dict()["_growth_tracker"] == sc.state_dict()["_growth_tracker"]
+    # classification loop + its checkpoint format
+    vm = _tiny_cls("fp16")
+    copt = FusedAdamW(vm, lr=1e-3, weight_decay=0.05)
+    csc = LossScaler(init_scale=4096.0)
+    cl = T.SyntheticLoader(4, 6, dev, seed=4)
+    c0 = T.train_epoch_cls(vm, cl, copt, dev, pos_weight=torch.tensor(1.0, device=dev), log_every=2, printer=None, loss_scaler=csc)
+    c1 = T.train_epoch_cls(vm, cl, copt, dev, pos_weight=torch.tensor(1.0, device=dev), log_every=2, printer=None, loss_scaler=csc)
+    assert c0.steps == 6 and c1.loss < c0.loss and csc.counters()["skipped"] == 0
+    path = T.save_cls_checkpoint(tmp_path / "run_e01_best.pth", 1, vm, copt, loss=c1.loss, extra={"val_loss": 0.5}, loss_scaler=csc)
+    assert torch.load(str(path), weights_only=False)["scaler_state_dict"]["scale"] == 4096.0
+    csc2 = LossScaler()
+    vm2 = _tiny_cls("fp16", seed=9)
+    vm2._rt.ensure(dev)
+    info = T.load_cls_checkpoint(tmp_path / "run", vm2, FusedAdamW(vm2, lr=1e-3), loss_scaler=csc2)
+    assert info.start_epoch == 2 and csc2.get_scale() == 4096.0
