@@ -149,7 +149,7 @@ def make_batch(workload, batch, device, rank, pool=False):
     return imgs, labels
 
 
-def make_step(workload, ddp, opt, imgs, labels, lr_every_step=False):
+def make_step(workload, ddp, opt, imgs, labels, lr_every_step=False, noise_buf=None):
     import ssl4polyp_amd as A
     pos_weight = torch.tensor(1.0, device=(imgs[0] if isinstance(imgs, (list, tuple)) else imgs).device)
     base_lr = [g["lr"] for g in opt.param_groups]
@@ -208,7 +208,9 @@ def make_step(workload, ddp, opt, imgs, labels, lr_every_step=False):
             im, lb = pick(im, lb)
             touch_lr()
             opt.zero_grad(set_to_none=True)
-            return finish(ddp(im, mask_ratio=0.75)[0])
+            # noise_buf: hipGraph replay -- the masking noise must come from a buffer the caller refills between replays (a draw
+            # inside the captured region would be baked into the graph)
+            return finish(ddp(im, mask_ratio=0.75, **({"noise": noise_buf} if noise_buf is not None else {}))[0])
     return step
 
 
@@ -740,13 +742,28 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
     imgs, labels = make_batch(workload, batch, device, rank, pool=not args.single_batch)
     pooled = isinstance(imgs, list)
     imgs0, labels0 = (imgs[0], labels[0]) if pooled else (imgs, labels)   # the batch of the parity block / the eval forward
-    eager_step = make_step(workload, ddp, opt, imgs, labels, args.lr_every_step)
     use_graph = args.graph == "on"  # auto: eager (measured faster: graph replay serialises the wgrad side stream)
     if use_graph:
+        # a captured step reads fixed addresses: ONE static batch / label / noise buffer, refilled from the resident pool before every
+        # replay (what a training loop over a graphed step does with each loader batch) -- the draws stay outside the graph
         from ssl4polyp_amd.graph import GraphedStep
+        s_imgs, s_labels = imgs0.clone(), labels0.clone()
+        noise_buf = torch.rand(batch, 196, device=device) if workload == "mae" else None
+        eager_step = make_step(workload, ddp, opt, s_imgs, s_labels, args.lr_every_step, noise_buf=noise_buf)
         graphed = GraphedStep(eager_step, opt, warmup=3)  # capture failures are fatal: no silent eager fallback
-        step = graphed.replay
+        tick = [0]
+
+        def step():
+            i = tick[0]
+            tick[0] = i + 1
+            if pooled:
+                s_imgs.copy_(imgs[i % len(imgs)])
+                s_labels.copy_(labels[i % labels.shape[0]])
+            if noise_buf is not None:
+                noise_buf.copy_(model._draw_noise(batch, device))
+            return graphed.replay()
     else:
+        eager_step = make_step(workload, ddp, opt, imgs, labels, args.lr_every_step)
         step = eager_step
 
     host_pool, host_gen = [], torch.Generator().manual_seed(1234 + rank)
