@@ -1536,6 +1536,10 @@ int few_tiles_threshold() {  // tuning hook, read once: PM_FEW_TILES=0 keeps eve
   static const int v = [] { const char* e = getenv("PM_FEW_TILES"); return e && e[0] ? atoi(e) : 128; }();
   return v;
 }
+int few_tiles_narrow_n() {  // tuning hook, read once: widest N for which the few-tiles rule ignores the cap on M
+  static const int v = [] { const char* e = getenv("PM_FEW_TILES_NARROW_N"); return e && e[0] ? atoi(e) : 512; }();
+  return v;
+}
 int few_tiles_max_m() {  // tuning hook, read once: largest M the few-tiles rule applies to
   static const int v = [] { const char* e = getenv("PM_FEW_TILES_MAXM"); return e && e[0] ? atoi(e) : 4096; }();
   return v;
@@ -1604,7 +1608,10 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
   // 128 x 128 kernel, the half-batch proj / fc2 of the fine-tune forward (M = 6 304) cost the step 4 % (MAE bs = 256: 1.6 %) although
   // they are faster alone -- two 66-KB workgroups on a CU keep the other chain's 128-KB ring workgroups off it -- while MAE at
   // bs = 64/GPU gains 4.5-6 %.  Hence the cap on M.
-  const bool few_tiles = (force_cfg & 63) == 0 && tiles256 < few_tiles_threshold() && M <= few_tiles_max_m();
+  // ... or narrow (N <= 512: the MAE decoder's proj / fc2 / dgrads at bs = 64/GPU, M = 6 304 / 12 608 -- 50 / 100 tiles; the same
+  // experiment: +0.7 % on top; a 512-wide problem never belongs to the fine-tune's or the bs = 256 encoder's half-batch chains).
+  const bool few_tiles = (force_cfg & 63) == 0 && tiles256 < few_tiles_threshold() &&
+                         (M <= few_tiles_max_m() || N <= few_tiles_narrow_n());
   // large-tile ring kernel: bf16, X k-normal (forward and dgrad GEMMs), big M
   if (is16(in_dtype) && !a_kmajor && (K % V3_KE) == 0 && M >= 1024 && (force_cfg & 63) != 1 && !few_tiles) {
     // Tile / pipeline choice, tuned on the ViT-B/16 shapes at M = 12608 (scratch/bench_gemm6.py).
