@@ -154,6 +154,24 @@ inline bool attn_head_major() {
   return v;
 }
 
+// Which (batch, head) problem a workgroup of the one-problem-per-workgroup kernels takes.  dh = 32 (the MAE decoder: 16 heads of 32):
+// a head's rows are 64-B pieces of the [B, N, 3, H, dh] rows -- HALF a cache line, the other half belongs to the neighbouring head.
+// The hardware deals workgroup ids to the 8 XCDs round-robin, so with the identity map heads 2p and 2p + 1 run on different XCDs and
+// each L2 fetches the whole line for its half (PMC, MAE bs = 256: 147.8 MB fetched by the forward against 77.5 MB of qkv, 496 MB by
+// the backward against 258 MB -- 1.9x; the dh = 64 kernels fetch 1.0x).  Map the two heads of a pair to workgroups b and b + 8: the
+// same XCD, dispatched back to back, so the second finds the lines in that XCD's L2.  Needs an even H and B H % 16 == 0 (else identity).
+template <int DH> __device__ __forceinline__ int problem_of_block(int bid, int nprob, int H) {
+  if constexpr (DH == 32) {
+#ifndef PM_ATTN_NO_PAIR_MAP
+    if ((nprob & 15) == 0 && (H & 1) == 0) {
+      const int xcd = bid & 7, j = bid >> 3;
+      return (((j >> 1) << 3) + xcd) * 2 + (j & 1);
+    }
+#endif
+  }
+  return bid;
+}
+
 // one wave per 32-row tile (7 waves for N = 197): every wave does identical work, nothing idles on a tail tile
 template <int NT> struct Waves { static constexpr int value = NT; };
 
@@ -172,7 +190,8 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_fwd_kernel(const T
   char* imgK = smem;
   char* imgV = smem + NT * 32 * RB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int prob = problem_of_block<DH>(blockIdx.x, gridDim.x, H);
+  const int b = prob / H, h = prob % H;
   const long ld = 3L * H * DH;
   const T* base = qkv + (long)b * N * ld + h * DH;
   load_image<T, DH>(imgK, base + H * DH, ld, N, NT * 32, tid, NW * 64);
@@ -255,7 +274,8 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const
   char* imgK = smem;
   char* imgV = smem + NT * 32 * RB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int prob = problem_of_block<DH>(blockIdx.x, gridDim.x, H);
+  const int b = prob / H, h = prob % H;
   const long ld = 3L * H * DH, ldo = (long)H * DH;
   const T* base = qkv + (long)b * N * ld + h * DH;
   load_image<T, DH>(imgK, base + H * DH, ld, N, NT * 32, tid, NW * 64);
@@ -328,7 +348,8 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(cons
   float* sl2 = reinterpret_cast<float*>(smem + 2 * NT * 32 * RB);  // lse * log2e per query
   float* sdl = sl2 + NT * 32;                                      // delta per query
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int prob = problem_of_block<DH>(blockIdx.x, gridDim.x, H);
+  const int b = prob / H, h = prob % H;
   const long ld = 3L * H * DH, ldo = (long)H * DH;
   const T* base = qkv + (long)b * N * ld + h * DH;
   load_image<T, DH>(imgQ, base, ld, N, NT * 32, tid, NW * 64);
@@ -573,7 +594,8 @@ __global__ __launch_bounds__(NT * 64) void attn_bwd_fused_kernel(const T* __rest
   float* sdl = sl2 + NT * 32;
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int prob = problem_of_block<DH>(blockIdx.x, gridDim.x, H);
+  const int b = prob / H, h = prob % H;
   const long ld = 3L * H * DH, ldo = (long)H * DH;   // (dqkv, out and dout stay token-major)
   const T* base = qkv + (long)b * lay.batch_stride + (long)h * lay.head_stride;
   const T* dobase = dout + (long)b * N * ldo + h * DH;
