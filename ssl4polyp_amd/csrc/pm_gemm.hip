@@ -61,7 +61,8 @@ struct GemmArgs {
   int ksteps_split;  // k-steps per split
   float* xsum;         // grouped wgrad: xsum[m] += sum_k X(m, k) (= the bias gradient: column sums of dY), or NULL
   int xsum_store;      // xsum[m] = ... instead of += (partial row sums of a k-slice, reduced later)
-  int col_major;       // tile index -> (tm, tn) column by column instead of row by row (grouped wgrad: see wgrad_group_kernel)
+  int col_major;       // tile index -> (tm, tn): 0 row by row, 1 column by column (grouped wgrad: see wgrad_group_kernel), >= 2: row by
+                       // row inside bands of that many tile columns (wide-N GEMMs: see gemm_dispatch)
 #ifdef PM_GEMM_STAMP
   unsigned long long* stamps;  // diagnostic build only: per-wave cycle sums of the k-loop segments
 #endif
@@ -658,7 +659,18 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
     }
   };
 #endif
-  const int tm = a.col_major ? tile % a.tiles_m : tile / a.tiles_n, tn = a.col_major ? tile / a.tiles_m : tile % a.tiles_n;
+  int tm, tn;
+  if (a.col_major >= 2) {  // bands of col_major tile columns, row by row inside a band (the last band may be narrower)
+    const int per_band = a.tiles_m * a.col_major;
+    const int band = tile / per_band, r = tile - band * per_band;
+    const int left = a.tiles_n - band * a.col_major;
+    const int bw = left < a.col_major ? left : a.col_major;
+    tm = r / bw;
+    tn = band * a.col_major + (r - tm * bw);
+  } else {
+    tm = a.col_major ? tile % a.tiles_m : tile / a.tiles_n;
+    tn = a.col_major ? tile / a.tiles_m : tile % a.tiles_n;
+  }
   const int m0 = tm * BM_, n0 = tn * BN_;
   const __bf16* X = reinterpret_cast<const __bf16*>(a.X);
   const __bf16* W = reinterpret_cast<const __bf16*>(a.W);
@@ -1536,6 +1548,10 @@ int few_tiles_threshold() {  // tuning hook, read once: PM_FEW_TILES=0 keeps eve
   static const int v = [] { const char* e = getenv("PM_FEW_TILES"); return e && e[0] ? atoi(e) : 128; }();
   return v;
 }
+int tile_band() {  // tuning hook, read once: forward / dgrad tiles walk bands of PM_TILE_BAND tile columns (default 6; 0: row by row)
+  static const int v = [] { const char* e = getenv("PM_TILE_BAND"); return e && e[0] ? atoi(e) : 6; }();
+  return v;
+}
 int few_tiles_narrow_n() {  // tuning hook, read once: widest N for which the few-tiles rule ignores the cap on M
   static const int v = [] { const char* e = getenv("PM_FEW_TILES_NARROW_N"); return e && e[0] ? atoi(e) : 512; }();
   return v;
@@ -1584,7 +1600,18 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
   a.split_k = 1;
   a.xsum = nullptr;
   a.xsum_store = 0;
+  // Tile order of a wide problem (experiment 11, round 4).  xcd_remap hands each XCD a contiguous run of tiles; row by row, a run of
+  // ~75 tiles of the dGELU dgrad (50 x 12 tiles) walks all 12 W panels (4.7 MB: more than the XCD's 4 MB L2, beside a 77-MB stream of
+  // saved pre-activations) six times -- PMC: 205.8 MB fetched per launch against ~135 MB if every XCD read W once.  In bands of 6 tile
+  // columns a run is ~12 row blocks x 6 panels: the band's W (2.4 MB) stays in the L2 while the row blocks stream through once.
+  // Measured (profiles/r4_exp11_tile_bands.txt): dGELU dgrad 205.7 -> 172.7 MB fetched, fc1 + GELU 67.5 -> 57.7 MB; stand-alone fc1 + GELU
+  // 99.5 -> 95.9 us; in the step +0.6 ... +1.2 % (cls), +0.7 % (MAE bs = 256), two same-box rounds each.
   a.col_major = 0;
+  {
+    const int band = tile_band();
+    const int tn256 = (N + 255) / 256;
+    if (band >= 2 && tn256 > band && !a_kmajor) a.col_major = band;
+  }
 #ifdef PM_GEMM_STAMP
   a.stamps = g_stamps;
 #endif
