@@ -47,7 +47,8 @@ int pm_abi_version(void);
 
 /* LayerNorm(eps) over the last dim -- replaces nn.LayerNorm in timm Block.norm1/norm2,
  * MaskedAutoencoderViT.norm / decoder_norm (models_mae.py:42,57,168,188).
- * x: f32 [M, D] with row stride ldx; y: out_dtype [M, D] contiguous; mean/rstd: f32 [M] (saved for backward). */
+ * x: f32 [M, D] with row stride ldx; y: out_dtype [M, D] contiguous; mean/rstd: f32 [M] (saved for backward).
+ * D <= 1280 (ViT-H), D % 4 == 0. */
 int pm_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y, int out_dtype,
                      float* mean, float* rstd, int M, int D, float eps, void* stream);
 
@@ -148,7 +149,7 @@ int pm_gemm_colsum(const void* A, long lda, int a_kmajor, const void* B, long ld
  * softmax(q k^T * dh^-0.5) v, never materialising the [N,N] scores in HBM.
  * qkv: act [B, N, 3, H, dh] (the qkv Linear's output as stored); out: act [B, N, H*dh];
  * lse: f32 [B, H, N] (log-sum-exp of the scaled scores, saved for backward).
- * Supported: dh in {32, 64}, N <= 224. */
+ * Supported: dh in {32, 64, 80} (ViT-B / MAE decoder / ViT-H), N <= 288 (257 = patch 14 at 224^2). */
 int pm_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int dh, int dtype, void* stream);
 /* Backward: dqkv [B,N,3,H,dh] from dout [B,N,H*dh]; delta: f32 workspace [B,H,N]. */
 int pm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
@@ -163,10 +164,21 @@ int pm_colsum_ws(const void* x, long ldx, int dtype, float* out, int M, int N, v
 
 /* Patch extraction (the im2col of timm PatchEmbed's Conv2d k=s=p), optionally only the kept patches
  * of MAE random masking (models_mae.py:141-142 applied BEFORE the projection, which is the same
- * linear map per patch): imgs f32 [B,C,Himg,Himg] NCHW -> cols act [B*keep, C*p*p] in (c,py,px) order.
+ * linear map per patch): imgs f32 [B,C,Himg,Himg] NCHW -> cols act [B*keep, ldcols], the first C*p*p of a row in (c,py,px)
+ * order, the rest zero (ldcols > C*p*p: the reduction dimension padded to the GEMM's k-step -- 3*14*14 = 588 -> 640 for
+ * mae_vit_huge_patch14, models_mae.py:239-244).  Any p that divides img (16-B reads when p % 4 == 0).
  * ids_keep: int32 [B, keep] patch indices, or NULL for all patches in raster order (keep = L). */
-int pm_patch_im2col(const float* imgs, const int* ids_keep, void* cols, int out_dtype, int B, int C, int img,
+int pm_patch_im2col(const float* imgs, const int* ids_keep, void* cols, long ldcols, int out_dtype, int B, int C, int img,
                     int p, int keep, void* stream);
+
+/* Zero-padded operand copy and its inverse, for a Linear whose reduction dimension is not a multiple of the matrix-core
+ * kernels' 16-byte chunks (patch 14: PatchEmbed.proj [D, 588], decoder_pred [588, Dd]; models_mae.py:36,57):
+ *   pm_pad_cast : dst act [rows_pad, ldd] <- src f32 [rows, lds] in the top-left corner, zeros elsewhere (up to cols_pad)
+ *   pm_unpad_add: dst f32 [rows, ldd] (+)= src f32 [rows, lds], the first `cols` columns (the valid part of a gradient
+ *                 computed in the padded layout; accumulate = 0 stores). */
+int pm_pad_cast(const float* src, long lds, void* dst, long ldd, int dst_dtype, int rows, int cols, int rows_pad,
+                int cols_pad, void* stream);
+int pm_unpad_add(const float* src, long lds, float* dst, long ldd, int rows, int cols, int accumulate, void* stream);
 
 /* Token assembly: x[b,0,:] = cls + pos[0]; x[b,1+j,:] = emb[b*keep+j,:] + pos[1+id(b,j),:]
  * (models_mae.py:155-163; models.py:198-201 / 28-33).  emb f32 [B*keep, D]; x f32 [B, 1+keep, D]. */
@@ -204,11 +216,11 @@ int pm_mae_unshuffle_bwd(const float* dout, const int* ids_shuffle, void* demb, 
 int pm_mae_loss_fwd(const float* imgs, const float* pred, long ldp, int has_cls_row, float* patch_loss, int B, int C,
                     int img, int p, int norm_pix, void* stream);
 int pm_mae_loss_finish(const float* patch_loss, const float* mask, long n, float* sums, float* loss, void* stream);
-/* Backward: dpred act-typed [B*(L+has_cls_row), p*p*C] contiguous, same row order as pred (cls rows and kept
- * patches zeroed); dloss f32 scalar on device. */
+/* Backward: dpred act-typed [B*(L+has_cls_row), lddp] (lddp >= p*p*C, a multiple of 4; columns beyond p*p*C zeroed),
+ * same row order as pred (cls rows and kept patches zeroed); dloss f32 scalar on device. */
 int pm_mae_loss_bwd(const float* imgs, const float* pred, long ldp, int has_cls_row, const float* mask,
-                    const float* sums, const float* dloss, void* dpred, int act_dtype, int B, int C, int img, int p,
-                    int norm_pix, void* stream);
+                    const float* sums, const float* dloss, void* dpred, long lddp, int act_dtype, int B, int C, int img,
+                    int p, int norm_pix, void* stream);
 
 /* f32 -> act cast (weight shadow copies for the bf16 MFMA path). */
 int pm_cast(const float* src, void* dst, int dst_dtype, long n, void* stream);

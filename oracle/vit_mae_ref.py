@@ -51,6 +51,8 @@ class ViTConfig:
 
 
 VIT_BASE = ViTConfig()
+VIT_LARGE = ViTConfig(embed_dim=1024, depth=24, num_heads=16)                  # models_mae.py:231-236
+VIT_HUGE = ViTConfig(patch_size=14, embed_dim=1280, depth=32, num_heads=16)    # models_mae.py:239-244
 # Small geometry used by the committed fixtures (weights travel in the fixture).
 VIT_TINY = ViTConfig(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2,
                      decoder_embed_dim=32, decoder_depth=1, decoder_num_heads=1)

@@ -33,7 +33,9 @@ SIGNATURES = {
     "pm_attention_bwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "pm_colsum": [P, L, I, P, I, I, P],
     "pm_colsum_ws": [P, L, I, P, I, I, P, ctypes.c_size_t, P],
-    "pm_patch_im2col": [P, P, P, I, I, I, I, I, I, P],
+    "pm_patch_im2col": [P, P, P, L, I, I, I, I, I, I, P],
+    "pm_pad_cast": [P, L, P, L, I, I, I, I, I, P],
+    "pm_unpad_add": [P, L, P, L, I, I, I, P],
     "pm_assemble_tokens": [P, P, P, P, P, I, I, I, P],
     "pm_assemble_tokens_bwd": [P, P, P, I, P, P, I, I, I, P],
     "pm_mae_noise": [P, L, ctypes.c_ulonglong, ctypes.c_uint, P],
@@ -42,7 +44,7 @@ SIGNATURES = {
     "pm_mae_unshuffle_bwd": [P, P, P, I, P, I, I, I, I, P, ctypes.c_size_t, P],
     "pm_mae_loss_fwd": [P, P, L, I, P, I, I, I, I, I, P],
     "pm_mae_loss_finish": [P, P, L, P, P, P],
-    "pm_mae_loss_bwd": [P, P, L, I, P, P, P, P, I, I, I, I, I, I, P],
+    "pm_mae_loss_bwd": [P, P, L, I, P, P, P, P, L, I, I, I, I, I, I, P],
     "pm_cast": [P, P, I, L, P],
     "pm_preprocess_u8": [P, P, P, I, I, I, F, F, F, F, F, F, P],
     "pm_aug_resize_u8": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],
@@ -69,7 +71,7 @@ SIGNATURES = {
     "pm_dgelu": [P, P, P, I, L, P],
 }
 
-ABI_VERSION = 10  # pm_abi_version() of the library these signatures describe
+ABI_VERSION = 11  # pm_abi_version() of the library these signatures describe
 PM_GROUP_WHOLE_K = -1  # pm_wgrad_group(max_blocks=...): never slice, whole-K 256x256 tiles
 
 WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4

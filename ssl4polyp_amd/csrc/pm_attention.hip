@@ -36,7 +36,16 @@ template <int RB> __device__ __forceinline__ int swz(int row) {
   // (4 consecutive rows per 16-lane group) are bank-conflict free.
   if constexpr (RB == 64) return (row >> 2) & 3;
   else if constexpr (RB == 128) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+  else if constexpr (RB == 384) return row & 7;   // 24 slots: the XOR must stay inside a group of 8
   else return row & 15;
+}
+
+// Bytes between rows of an LDS image of DH-element rows.  dh = 32 / 64: the row itself.  dh = 80 (ViT-H: 1280 / 16 heads) is
+// not a power of two: the row is padded to a pitch the chunk swizzle covers (16-bit: 128 elements = 256 B, 16 slots; f32: 96
+// elements = 384 B, 24 slots); the products run over 5 k-steps of 16 (10 of 8 in f32) and 3 output tiles of 32 features, the
+// last one half padding (zeros in the image, never stored).
+template <typename T, int DH> constexpr int row_bytes() {
+  return DH == 80 ? (sizeof(T) == 2 ? 256 : 384) : DH * (int)sizeof(T);
 }
 
 // Stage `rows_valid` rows of DH elements (global row stride `ld` elements) into an LDS image of `rows_total`
@@ -44,13 +53,14 @@ template <int RB> __device__ __forceinline__ int swz(int row) {
 template <typename T, int DH>
 __device__ __forceinline__ void load_image(char* img, const T* __restrict__ src, long ld, int rows_valid,
                                            int rows_total, int tid, int nthreads) {
-  constexpr int RB = DH * sizeof(T);
-  constexpr int CPR = RB / 16;
+  constexpr int RB = row_bytes<T, DH>();
+  constexpr int CPV = DH * sizeof(T) / 16;                      // 16-B chunks a row has in memory
+  constexpr int CPF = ((DH + 31) / 32) * 32 * sizeof(T) / 16;   // chunks the products read (== CPV unless dh = 80)
   constexpr int EPC = 16 / sizeof(T);
-  for (int id = tid; id < rows_total * CPR; id += nthreads) {
-    const int row = id / CPR, c = id % CPR;
+  for (int id = tid; id < rows_total * CPF; id += nthreads) {
+    const int row = id / CPF, c = id % CPF;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < rows_valid) v = *reinterpret_cast<const u32x4*>(src + (long)row * ld + c * EPC);
+    if (row < rows_valid && c < CPV) v = *reinterpret_cast<const u32x4*>(src + (long)row * ld + c * EPC);
     *reinterpret_cast<u32x4*>(img + row * RB + 16 * (c ^ swz<RB>(row))) = v;
   }
 }
@@ -58,7 +68,7 @@ __device__ __forceinline__ void load_image(char* img, const T* __restrict__ src,
 // Row-read fragment: rows rb..rb+31 on lanes (l&31), k-step kk (chunk 2*kk + h).
 template <typename T, int DH>
 __device__ __forceinline__ Frag16 frag_rows(const char* img, int rb, int kk, int lane) {
-  constexpr int RB = DH * sizeof(T);
+  constexpr int RB = row_bytes<T, DH>();
   const int row = rb + (lane & 31);
   const int c = 2 * kk + (lane >> 5);
   Frag16 f;
@@ -80,7 +90,7 @@ __device__ __forceinline__ Frag16 frag_global(const T* __restrict__ rowptr, bool
 // where X is a 32x32 accumulator tile (rows in registers, column on the lane) used as the B operand.
 template <typename T, int DH>
 __device__ __forceinline__ f32x16 mma_imgT_acc(const char* PM_LDS_IMAGE img, int rb, int d0, const f32x16& x, f32x16 acc, int lane) {
-  constexpr int RB = DH * sizeof(T);
+  constexpr int RB = row_bytes<T, DH>();
   if constexpr (sizeof(T) == 2) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, hh = g >> 1;
     const int col = d0 + 16 * (g & 1) + 4 * p;
@@ -122,17 +132,21 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
-// Store an accumulator tile whose lane is a token row and whose registers are 32 consecutive features.
+// Store an accumulator tile whose lane is a token row and whose registers are 32 consecutive features (the first `ncols` of
+// them exist: 16 for the last tile of an 80-wide head).
 template <typename T>
-__device__ __forceinline__ void store_tile_T(T* __restrict__ rowptr, bool valid, const f32x16& acc, float scale, int lane) {
+__device__ __forceinline__ void store_tile_T(T* __restrict__ rowptr, bool valid, const f32x16& acc, float scale, int lane,
+                                             int ncols = 32) {
   if (!valid) return;
   const int hh = lane >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     f32x4 v = {acc[4 * g] * scale, acc[4 * g + 1] * scale, acc[4 * g + 2] * scale, acc[4 * g + 3] * scale};
-    store4<T>(rowptr + 8 * g + 4 * hh, v);
+    if (8 * g + 4 * hh < ncols) store4<T>(rowptr + 8 * g + 4 * hh, v);
   }
 }
+// features of output tile dt that exist
+template <int DH> __device__ __forceinline__ constexpr int tile_cols(int dt) { return DH - 32 * dt < 32 ? DH - 32 * dt : 32; }
 
 constexpr float kLog2e = 1.4426950408889634f;
 
@@ -175,48 +189,63 @@ template <int DH> __device__ __forceinline__ int problem_of_block(int bid, int n
 // one wave per 32-row tile (7 waves for N = 197): every wave does identical work, nothing idles on a tail tile
 template <int NT> struct Waves { static constexpr int value = NT; };
 
+// Tiles of the OTHER side of the product an LDS image pair holds at a time.  Normally all NT of them (one staging, one barrier).
+// f32 rows of an 80-wide head at N = 257 (ViT-H/14 at 224^2) would need 2 x 288 x 384 B = 216 KiB: the images are then staged
+// in chunks of CT tiles, the per-wave state (running max / sum and O^T; dQ^T; dK^T and dV^T) living in registers across chunks.
+template <typename T, int DH, int NT> constexpr int chunk_tiles() {
+  constexpr int per_tile = 2 * 32 * row_bytes<T, DH>() + 2 * 32 * (int)sizeof(float);
+  if (NT * per_tile <= 150 * 1024) return NT;
+  return (80 * 1024) / per_tile;   // two workgroups per CU
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <typename T, int DH, int NT>
+template <typename T, int DH, int NT, int CT>
 __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                                         float* __restrict__ lse, int N, int H,
                                                                         float scale) {
-  constexpr int RB = DH * sizeof(T);
-  constexpr int KS = RB / 32;   // 16-B fragment pairs along the head dim
-  constexpr int DT = DH / 32;   // 32-wide output tiles along the head dim
+  constexpr int RB = row_bytes<T, DH>();
+  constexpr int KS = DH * sizeof(T) / 32;   // 16-B fragment pairs along the head dim
+  constexpr int DT = (DH + 31) / 32;        // 32-wide output tiles along the head dim
   constexpr int NW = Waves<NT>::value;
+  static_assert(NW == NT, "one wave per query tile: its softmax state stays in registers across key chunks");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* imgK = smem;
-  char* imgV = smem + NT * 32 * RB;
+  char* imgV = smem + CT * 32 * RB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int prob = problem_of_block<DH>(blockIdx.x, gridDim.x, H);
   const int b = prob / H, h = prob % H;
   const long ld = 3L * H * DH;
   const T* base = qkv + (long)b * N * ld + h * DH;
-  load_image<T, DH>(imgK, base + H * DH, ld, N, NT * 32, tid, NW * 64);
-  load_image<T, DH>(imgV, base + 2 * H * DH, ld, N, NT * 32, tid, NW * 64);
-  __syncthreads();
   const float c = scale * kLog2e;
-  for (int qt = wave; qt < NT; qt += NW) {
-    const int q = qt * 32 + (lane & 31);
-    const bool qv = q < N;
-    Frag16 fq[KS];
+  const int q = wave * 32 + (lane & 31);
+  const bool qv = q < N;
+  // online softmax over the key tiles: running max m (shared by the two lane halves of a query), running
+  // sum l, O^T rescaled by exp2((m_old - m_new) c) -- only 16 score registers are live at a time.
+  Frag16 fq[KS];
+  f32x16 o[DT];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) fq[kk] = frag_global<T>(base + (long)q * ld, qv, kk, lane);
-    // online softmax over the key tiles: running max m (shared by the two lane halves of a query), running
-    // sum l, O^T rescaled by exp2((m_old - m_new) c) -- only 16 score registers are live at a time.
-    f32x16 o[DT];
+  for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
+  float m = -INFINITY, l = 0.f;
+  for (int c0 = 0; c0 < NT; c0 += CT) {
+    if (c0) __syncthreads();  // every wave is done with the previous chunk's images
+    load_image<T, DH>(imgK, base + H * DH + (long)c0 * 32 * ld, ld, N - c0 * 32, CT * 32, tid, NW * 64);
+    load_image<T, DH>(imgV, base + 2 * H * DH + (long)c0 * 32 * ld, ld, N - c0 * 32, CT * 32, tid, NW * 64);
+    __syncthreads();
+    if (c0 == 0) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
-    float m = -INFINITY, l = 0.f;
+      for (int kk = 0; kk < KS; ++kk) fq[kk] = frag_global<T>(base + (long)q * ld, qv, kk, lane);
+    }
+    const int cend = c0 + CT < NT ? c0 + CT : NT;
 #pragma unroll 1
-    for (int kt = 0; kt < NT; ++kt) {
+    for (int kt = c0; kt < cend; ++kt) {
+      const int rb = (kt - c0) * 32;
       f32x16 s = zero16();
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) s = mfma16B<T>(frag_rows<T, DH>(imgK, kt * 32, kk, lane), fq[kk], s);
+      for (int kk = 0; kk < KS; ++kk) s = mfma16B<T>(frag_rows<T, DH>(imgK, rb, kk, lane), fq[kk], s);
       float tm = -INFINITY;
-      if (kt == NT - 1) {  // only the last key tile holds padded keys (zero rows of the K image): mask them out
+      if (kt * 32 + 32 > N) {  // a tile with padded keys (zero rows of the K image; N = 100 on seven tiles has four of them): mask
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kt * 32 + acc_row(r, hh);
@@ -244,75 +273,82 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_fwd_kernel(const T
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
-        o[dt] = mma_imgT_acc<T, DH>(imgV, kt * 32, dt * 32, s, o[dt], lane);
+        o[dt] = mma_imgT_acc<T, DH>(imgV, rb, dt * 32, s, o[dt], lane);
       }
     }
-    l += __shfl_xor(l, 32, 64);
-    if (qv && hh == 0) lse[((long)b * H + h) * N + q] = m * scale + __logf(l);
-    const float inv = 1.0f / l;
-    T* orow = out + ((long)b * N + q) * H * DH + h * DH;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) store_tile_T<T>(orow + dt * 32, qv, o[dt], inv, lane);
   }
+  l += __shfl_xor(l, 32, 64);
+  if (qv && hh == 0) lse[((long)b * H + h) * N + q] = m * scale + __logf(l);
+  const float inv = 1.0f / l;
+  T* orow = out + ((long)b * N + q) * H * DH + h * DH;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) store_tile_T<T>(orow + dt * 32, qv, o[dt], inv, lane, tile_cols<DH>(dt));
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward, query side: dQ (and delta = rowsum(dO * O), written for the key-side kernel)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int DH, int NT>
+template <typename T, int DH, int NT, int CT>
 __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const T* __restrict__ qkv, const T* __restrict__ out,
                                                                           const T* __restrict__ dout,
                                                                           const float* __restrict__ lse,
                                                                           float* __restrict__ delta, T* __restrict__ dqkv,
                                                                           int N, int H, float scale) {
-  constexpr int RB = DH * sizeof(T);
-  constexpr int KS = RB / 32;
-  constexpr int DT = DH / 32;
+  constexpr int RB = row_bytes<T, DH>();
+  constexpr int KS = DH * sizeof(T) / 32;
+  constexpr int DT = (DH + 31) / 32;
   constexpr int NW = Waves<NT>::value;
   constexpr int EPC = 16 / sizeof(T);
+  static_assert(NW == NT, "one wave per query tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* imgK = smem;
-  char* imgV = smem + NT * 32 * RB;
+  char* imgV = smem + CT * 32 * RB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int prob = problem_of_block<DH>(blockIdx.x, gridDim.x, H);
   const int b = prob / H, h = prob % H;
   const long ld = 3L * H * DH, ldo = (long)H * DH;
   const T* base = qkv + (long)b * N * ld + h * DH;
-  load_image<T, DH>(imgK, base + H * DH, ld, N, NT * 32, tid, NW * 64);
-  load_image<T, DH>(imgV, base + 2 * H * DH, ld, N, NT * 32, tid, NW * 64);
-  __syncthreads();
   const float c = scale * kLog2e;
-  for (int qt = wave; qt < NT; qt += NW) {
-    const int q = qt * 32 + (lane & 31);
-    const bool qv = q < N;
-    const T* orow = out + ((long)b * N + q) * ldo + h * DH;
-    const T* dorow = dout + ((long)b * N + q) * ldo + h * DH;
-    Frag16 fq[KS], fdo[KS];
-    float dl = 0.f;
+  const int q = wave * 32 + (lane & 31);
+  const bool qv = q < N;
+  const long sidx = ((long)b * H + h) * N + q;
+  Frag16 fq[KS], fdo[KS];
+  float l2 = 0.f, dls = 0.f;
+  f32x16 dq[DT];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      fq[kk] = frag_global<T>(base + (long)q * ld, qv, kk, lane);
-      fdo[kk] = frag_global<T>(dorow, qv, kk, lane);
-      const Frag16 fo = frag_global<T>(orow, qv, kk, lane);
+  for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
+  for (int c0 = 0; c0 < NT; c0 += CT) {
+    if (c0) __syncthreads();
+    load_image<T, DH>(imgK, base + H * DH + (long)c0 * 32 * ld, ld, N - c0 * 32, CT * 32, tid, NW * 64);
+    load_image<T, DH>(imgV, base + 2 * H * DH + (long)c0 * 32 * ld, ld, N - c0 * 32, CT * 32, tid, NW * 64);
+    __syncthreads();
+    if (c0 == 0) {
+      const T* orow = out + ((long)b * N + q) * ldo + h * DH;
+      const T* dorow = dout + ((long)b * N + q) * ldo + h * DH;
+      float dl = 0.f;
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) dl += frag_get<T>(fdo[kk], e) * frag_get<T>(fo, e);
+      for (int kk = 0; kk < KS; ++kk) {
+        fq[kk] = frag_global<T>(base + (long)q * ld, qv, kk, lane);
+        fdo[kk] = frag_global<T>(dorow, qv, kk, lane);
+        const Frag16 fo = frag_global<T>(orow, qv, kk, lane);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) dl += frag_get<T>(fdo[kk], e) * frag_get<T>(fo, e);
+      }
+      dl += __shfl_xor(dl, 32, 64);
+      if (qv && hh == 0) delta[sidx] = dl;
+      l2 = qv ? lse[sidx] * kLog2e : 0.f;
+      dls = dl * scale;
     }
-    dl += __shfl_xor(dl, 32, 64);
-    const long sidx = ((long)b * H + h) * N + q;
-    if (qv && hh == 0) delta[sidx] = dl;
-    const float l2 = qv ? lse[sidx] * kLog2e : 0.f;
-    const float dls = dl * scale;
-    f32x16 dq[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
+    const int cend = c0 + CT < NT ? c0 + CT : NT;
     // dh = 32: two key tiles in flight per wave (the loop is a latency chain; registers allow it: 80 VGPRs)
 #pragma unroll kTileUnroll<DH>
-    for (int kt = 0; kt < NT; ++kt) {
+    for (int kt = c0; kt < cend; ++kt) {
+      const int rb = (kt - c0) * 32;
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
-        s = mfma16B<T>(frag_rows<T, DH>(imgK, kt * 32, kk, lane), fq[kk], s);
-        dp = mfma16B<T>(frag_rows<T, DH>(imgV, kt * 32, kk, lane), fdo[kk], dp);
+        s = mfma16B<T>(frag_rows<T, DH>(imgK, rb, kk, lane), fq[kk], s);
+        dp = mfma16B<T>(frag_rows<T, DH>(imgV, rb, kk, lane), fdo[kk], dp);
       }
       // no masking: a padded key has a zero K row, so its dS is multiplied by zeros in the dQ product below -- PROVIDED it
       // is finite: its score is 0, so P = exp2(0 - l2) overflows once the row's log-sum-exp drops below -88 (every real
@@ -322,75 +358,82 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_q_kernel(const
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fminf(s[r] * c - l2, 0.f)) * (dp[r] * scale - dls);  // dS^T
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) dq[dt] = mma_imgT_acc<T, DH>(imgK, kt * 32, dt * 32, s, dq[dt], lane);
+      for (int dt = 0; dt < DT; ++dt) dq[dt] = mma_imgT_acc<T, DH>(imgK, rb, dt * 32, s, dq[dt], lane);
     }
-    T* dqrow = dqkv + ((long)b * N + q) * ld + h * DH;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) store_tile_T<T>(dqrow + dt * 32, qv, dq[dt], 1.0f, lane);
   }
+  T* dqrow = dqkv + ((long)b * N + q) * ld + h * DH;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) store_tile_T<T>(dqrow + dt * 32, qv, dq[dt], 1.0f, lane, tile_cols<DH>(dt));
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward, key side: dK and dV
 // ------------------------------------------------------------------------------------------------
-template <typename T, int DH, int NT>
+template <typename T, int DH, int NT, int CT>
 __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                                            const float* __restrict__ lse,
                                                                            const float* __restrict__ delta,
                                                                            T* __restrict__ dqkv, int N, int H, float scale) {
-  constexpr int RB = DH * sizeof(T);
-  constexpr int KS = RB / 32;
-  constexpr int DT = DH / 32;
+  constexpr int RB = row_bytes<T, DH>();
+  constexpr int KS = DH * sizeof(T) / 32;
+  constexpr int DT = (DH + 31) / 32;
   constexpr int NW = Waves<NT>::value;
+  static_assert(NW == NT, "one wave per key tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* imgQ = smem;
-  char* imgDO = smem + NT * 32 * RB;
-  float* sl2 = reinterpret_cast<float*>(smem + 2 * NT * 32 * RB);  // lse * log2e per query
-  float* sdl = sl2 + NT * 32;                                      // delta per query
+  char* imgDO = smem + CT * 32 * RB;
+  float* sl2 = reinterpret_cast<float*>(smem + 2 * CT * 32 * RB);  // lse * log2e per query of the chunk
+  float* sdl = sl2 + CT * 32;                                      // delta * scale per query of the chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int prob = problem_of_block<DH>(blockIdx.x, gridDim.x, H);
   const int b = prob / H, h = prob % H;
   const long ld = 3L * H * DH, ldo = (long)H * DH;
   const T* base = qkv + (long)b * N * ld + h * DH;
-  load_image<T, DH>(imgQ, base, ld, N, NT * 32, tid, NW * 64);
-  load_image<T, DH>(imgDO, dout + (long)b * N * ldo + h * DH, ldo, N, NT * 32, tid, NW * 64);
-  for (int i = tid; i < NT * 32; i += NW * 64) {
-    const long sidx = ((long)b * H + h) * N + i;
-    sl2[i] = i < N ? lse[sidx] * kLog2e : 0.f;
-    sdl[i] = i < N ? delta[sidx] * scale : 0.f;
-  }
-  __syncthreads();
   const float c = scale * kLog2e;
-  for (int kt = wave; kt < NT; kt += NW) {
-    const int key = kt * 32 + (lane & 31);
-    const bool kv = key < N;
-    Frag16 fk[KS], fv[KS];
+  const int key = wave * 32 + (lane & 31);
+  const bool kv = key < N;
+  Frag16 fk[KS], fv[KS];
+  f32x16 dk[DT], dv[DT];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      fk[kk] = frag_global<T>(base + (long)key * ld + H * DH, kv, kk, lane);
-      fv[kk] = frag_global<T>(base + (long)key * ld + 2 * H * DH, kv, kk, lane);
+  for (int dt = 0; dt < DT; ++dt) {
+    dk[dt] = zero16();
+    dv[dt] = zero16();
+  }
+  for (int c0 = 0; c0 < NT; c0 += CT) {
+    if (c0) __syncthreads();
+    load_image<T, DH>(imgQ, base + (long)c0 * 32 * ld, ld, N - c0 * 32, CT * 32, tid, NW * 64);
+    load_image<T, DH>(imgDO, dout + ((long)b * N + c0 * 32) * ldo + h * DH, ldo, N - c0 * 32, CT * 32, tid, NW * 64);
+    for (int i = tid; i < CT * 32; i += NW * 64) {
+      const int qi = c0 * 32 + i;
+      const long sidx = ((long)b * H + h) * N + qi;
+      sl2[i] = qi < N ? lse[sidx] * kLog2e : 0.f;
+      sdl[i] = qi < N ? delta[sidx] * scale : 0.f;
     }
-    f32x16 dk[DT], dv[DT];
+    __syncthreads();
+    if (c0 == 0) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      dk[dt] = zero16();
-      dv[dt] = zero16();
+      for (int kk = 0; kk < KS; ++kk) {
+        fk[kk] = frag_global<T>(base + (long)key * ld + H * DH, kv, kk, lane);
+        fv[kk] = frag_global<T>(base + (long)key * ld + 2 * H * DH, kv, kk, lane);
+      }
     }
+    const int cend = c0 + CT < NT ? c0 + CT : NT;
 #pragma unroll kTileUnroll<DH>
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = c0; qt < cend; ++qt) {
+      const int rb = (qt - c0) * 32;
       f32x16 s = zero16(), dp = zero16();
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
-        s = mfma16B<T>(frag_rows<T, DH>(imgQ, qt * 32, kk, lane), fk[kk], s);
-        dp = mfma16B<T>(frag_rows<T, DH>(imgDO, qt * 32, kk, lane), fv[kk], dp);
+        s = mfma16B<T>(frag_rows<T, DH>(imgQ, rb, kk, lane), fk[kk], s);
+        dp = mfma16B<T>(frag_rows<T, DH>(imgDO, rb, kk, lane), fv[kk], dp);
       }
       // no masking: a padded query has zero Q and dO rows (and lse = delta = 0 in LDS), so its finite P / dS rows
       // meet zeros in both products below; a padded key's lane is never stored.  sdl holds delta * scale.
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are queries qt*32 + 8g + 4hh + 0..3: one 16-B LDS read each
-        const int q = qt * 32 + 8 * g + 4 * hh;
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl2 + q);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sdl + q);
+        const int qq = rb + 8 * g + 4 * hh;
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl2 + qq);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(sdl + qq);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
@@ -401,16 +444,16 @@ __global__ __launch_bounds__(Waves<NT>::value * 64) void attn_bwd_kv_kernel(cons
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        dv[dt] = mma_imgT_acc<T, DH>(imgDO, qt * 32, dt * 32, s, dv[dt], lane);
-        dk[dt] = mma_imgT_acc<T, DH>(imgQ, qt * 32, dt * 32, dp, dk[dt], lane);
+        dv[dt] = mma_imgT_acc<T, DH>(imgDO, rb, dt * 32, s, dv[dt], lane);
+        dk[dt] = mma_imgT_acc<T, DH>(imgQ, rb, dt * 32, dp, dk[dt], lane);
       }
     }
-    T* drow = dqkv + ((long)b * N + key) * ld + h * DH;
+  }
+  T* drow = dqkv + ((long)b * N + key) * ld + h * DH;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      store_tile_T<T>(drow + H * DH + dt * 32, kv, dk[dt], 1.0f, lane);
-      store_tile_T<T>(drow + 2 * H * DH + dt * 32, kv, dv[dt], 1.0f, lane);
-    }
+  for (int dt = 0; dt < DT; ++dt) {
+    store_tile_T<T>(drow + H * DH + dt * 32, kv, dk[dt], 1.0f, lane, tile_cols<DH>(dt));
+    store_tile_T<T>(drow + 2 * H * DH + dt * 32, kv, dv[dt], 1.0f, lane, tile_cols<DH>(dt));
   }
 }
 
@@ -547,9 +590,10 @@ int launch_fwd2(const void* qkv, void* out, float* lse, int B, int N, int H, hip
 template <typename T, int DH, int NT>
 int launch_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t s) {
   constexpr int NW = Waves<NT>::value;
-  const size_t lds = 2 * NT * 32 * DH * sizeof(T);
+  constexpr int CT = chunk_tiles<T, DH, NT>();
+  const size_t lds = 2 * CT * 32 * row_bytes<T, DH>();
   const float scale = 1.0f / sqrtf((float)DH);
-  auto kern = attn_fwd_kernel<T, DH, NT>;
+  auto kern = attn_fwd_kernel<T, DH, NT, CT>;
   PM_ALLOW_LDS(kern, lds);
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(NW * 64), lds, s, (const T*)qkv, (T*)out, lse, N, H, scale);
   return pm_check_launch();
@@ -749,18 +793,20 @@ int dispatch_bwd_fused(int nt, const void* qkv, const void* out, const void* dou
                        int H, hipStream_t s) {
   if (nt <= 1) return launch_bwd_fused<T, DH, 1>(qkv, out, dout, lse, dqkv, B, N, H, s);
   if (nt <= 2) return launch_bwd_fused<T, DH, 2>(qkv, out, dout, lse, dqkv, B, N, H, s);
-  return launch_bwd_fused<T, DH, 7>(qkv, out, dout, lse, dqkv, B, N, H, s);
+  if (nt <= 7) return launch_bwd_fused<T, DH, 7>(qkv, out, dout, lse, dqkv, B, N, H, s);
+  return launch_bwd_fused<T, DH, 9>(qkv, out, dout, lse, dqkv, B, N, H, s);   // N = 257: patch 14 at 224^2 (4 x 36 KiB images)
 }
 
 template <typename T, int DH, int NT>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
                int N, int H, hipStream_t s) {
   constexpr int NW = Waves<NT>::value;
-  const size_t lds = 2 * NT * 32 * DH * sizeof(T);
-  const size_t lds_kv = lds + 2 * NT * 32 * sizeof(float);
+  constexpr int CT = chunk_tiles<T, DH, NT>();
+  const size_t lds = 2 * CT * 32 * row_bytes<T, DH>();
+  const size_t lds_kv = lds + 2 * CT * 32 * sizeof(float);
   const float scale = 1.0f / sqrtf((float)DH);
-  auto kq = attn_bwd_q_kernel<T, DH, NT>;
-  auto kkv = attn_bwd_kv_kernel<T, DH, NT>;
+  auto kq = attn_bwd_q_kernel<T, DH, NT, CT>;
+  auto kkv = attn_bwd_kv_kernel<T, DH, NT, CT>;
   PM_ALLOW_LDS(kq, lds);
   PM_ALLOW_LDS(kkv, lds_kv);
   hipLaunchKernelGGL(kq, dim3(B * H), dim3(NW * 64), lds, s, (const T*)qkv, (const T*)out, (const T*)dout, lse, delta,
@@ -772,16 +818,28 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
 
 template <typename T, int DH>
 int dispatch_fwd(int nt, const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t s) {
-  if (nt <= 1) return launch_fwd<T, DH, 1>(qkv, out, lse, B, N, H, s);
-  if (nt <= 2) return launch_fwd<T, DH, 2>(qkv, out, lse, B, N, H, s);
-  return launch_fwd<T, DH, 7>(qkv, out, lse, B, N, H, s);
+  if constexpr (DH == 80) {  // ViT-H: N = 65 under MAE masking, 257 unmasked
+    if (nt <= 3) return launch_fwd<T, DH, 3>(qkv, out, lse, B, N, H, s);
+    return launch_fwd<T, DH, 9>(qkv, out, lse, B, N, H, s);
+  } else {
+    if (nt <= 1) return launch_fwd<T, DH, 1>(qkv, out, lse, B, N, H, s);
+    if (nt <= 2) return launch_fwd<T, DH, 2>(qkv, out, lse, B, N, H, s);
+    if (nt <= 7) return launch_fwd<T, DH, 7>(qkv, out, lse, B, N, H, s);
+    return launch_fwd<T, DH, 9>(qkv, out, lse, B, N, H, s);
+  }
 }
 template <typename T, int DH>
 int dispatch_bwd(int nt, const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                  int B, int N, int H, hipStream_t s) {
-  if (nt <= 1) return launch_bwd<T, DH, 1>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
-  if (nt <= 2) return launch_bwd<T, DH, 2>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
-  return launch_bwd<T, DH, 7>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+  if constexpr (DH == 80) {
+    if (nt <= 3) return launch_bwd<T, DH, 3>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+    return launch_bwd<T, DH, 9>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+  } else {
+    if (nt <= 1) return launch_bwd<T, DH, 1>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+    if (nt <= 2) return launch_bwd<T, DH, 2>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+    if (nt <= 7) return launch_bwd<T, DH, 7>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+    return launch_bwd<T, DH, 9>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+  }
 }
 
 // A/B switch for the tuning scripts (PM_ATTN_V1=1: the one-block-per-head kernels everywhere); read once.
@@ -796,8 +854,8 @@ bool attn_fwd2_dh32() {  // the persistent forward for the 32-wide MAE decoder h
 
 inline int check_shape(int B, int N, int H, int dh, int dtype) {
   if (B <= 0 || N <= 0 || H <= 0) return PM_ESHAPE;
-  if (N > 224) return PM_ESHAPE;
-  if (dh != 32 && dh != 64) return PM_ESHAPE;
+  if (N > 288) return PM_ESHAPE;
+  if (dh != 32 && dh != 64 && dh != 80) return PM_ESHAPE;
   if (dtype != PM_BF16 && dtype != PM_F16 && dtype != PM_F32) return PM_EINVAL;
   return PM_OK;
 }
@@ -817,9 +875,11 @@ extern "C" int pm_attention_fwd(const void* qkv, void* out, float* lse, int B, i
     PM_DISPATCH_16(dtype, T, {
       if (nt == 7 && dh == 64 && !attn_v1()) return launch_fwd2<T, 64>(qkv, out, lse, B, N, H, s);
       if (nt == 7 && dh == 32 && attn_fwd2_dh32()) return launch_fwd2<T, 32>(qkv, out, lse, B, N, H, s);
+      if (dh == 80) return dispatch_fwd<T, 80>(nt, qkv, out, lse, B, N, H, s);
       return dh == 64 ? dispatch_fwd<T, 64>(nt, qkv, out, lse, B, N, H, s) : dispatch_fwd<T, 32>(nt, qkv, out, lse, B, N, H, s);
     });
   }
+  if (dh == 80) return dispatch_fwd<float, 80>(nt, qkv, out, lse, B, N, H, s);
   return dh == 64 ? dispatch_fwd<float, 64>(nt, qkv, out, lse, B, N, H, s)
                   : dispatch_fwd<float, 32>(nt, qkv, out, lse, B, N, H, s);
 }
@@ -833,6 +893,8 @@ extern "C" int pm_attention_bwd(const void* qkv, const void* out, const void* do
   hipStream_t s = pm_stream(stream);
   if (dtype != PM_F32) {
     PM_DISPATCH_16(dtype, T, {
+      // 80-wide heads (ViT-H): the two-kernel form (the fused kernel's four images of 288 x 256 B would not fit the LDS)
+      if (dh == 80) return dispatch_bwd<T, 80>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s);
       if (!attn_v1())
         return dh == 64 ? dispatch_bwd_fused<T, 64>(nt, qkv, out, dout, lse, dqkv, B, N, H, s)
                         : dispatch_bwd_fused<T, 32>(nt, qkv, out, dout, lse, dqkv, B, N, H, s);
@@ -840,6 +902,7 @@ extern "C" int pm_attention_bwd(const void* qkv, const void* out, const void* do
                       : dispatch_bwd<T, 32>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s);
     });
   }
+  if (dh == 80) return dispatch_bwd<float, 80>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s);
   return dh == 64 ? dispatch_bwd<float, 64>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
                   : dispatch_bwd<float, 32>(nt, qkv, out, dout, lse, delta, dqkv, B, N, H, s);
 }

@@ -1,20 +1,22 @@
 // pm_layernorm.hip -- LayerNorm forward / backward for the pre-LN ViT blocks (HBM-bound).
 // Replaces nn.LayerNorm(eps=1e-6) of timm Block.norm1/norm2 and MaskedAutoencoderViT.norm/decoder_norm
 // (reference models_mae.py:39-42,53-57,168,188).  One wave64 per row, the row lives in registers
-// (D <= 1024, D % 4 == 0: 768 / 512 for ViT-B/16 and its MAE decoder), f32 statistics, two-pass variance.
+// (D <= 1280, D % 4 == 0: 768 / 512 for ViT-B/16 and its MAE decoder, 1024 / 1280 for ViT-L / ViT-H; the number of f32x4 slots
+// per lane is a template parameter), f32 statistics, two-pass variance.
 // Algorithmic bytes per row: fwd 4D (x) + sizeof(act)*D (y); bwd sizeof(act)*D (dy) + 4D (x) + 4D (dres)
 // + 4D (dx) + sizeof(act)*D (dx_act).
 #include "pm_common.h"
 
 namespace {
 
-constexpr int kMaxVec = 4;  // f32x4 per lane -> D <= 4*64*4 = 1024
+constexpr int kMaxD = 1280;  // 5 f32x4 slots per lane (ViT-H)
 
-template <typename TOut>
+template <typename TOut, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, TOut* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int M,
                                                      int D, float eps) {
+  constexpr int kMaxVec = NV;  // f32x4 slots per lane for this D: D <= 256 * NV
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nvec = D >> 2;
@@ -229,10 +231,14 @@ inline int ln_grid(int M) {
 extern "C" int pm_layernorm_fwd(const float* x, long ldx, const float* gamma, const float* beta, void* y, int out_dtype,
                                 float* mean, float* rstd, int M, int D, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd) return PM_EINVAL;
-  if (M <= 0 || D <= 0 || D > 1024 || (D & 3) || (ldx & 3)) return PM_ESHAPE;
+  if (M <= 0 || D <= 0 || D > kMaxD || (D & 3) || (ldx & 3)) return PM_ESHAPE;
   const int grid = (M + 3) / 4 > 4096 ? 4096 : (M + 3) / 4;
-  PM_DISPATCH_ACT(out_dtype, T, hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(grid), dim3(256), 0, pm_stream(stream), x, ldx, gamma,
-                                                   beta, (T*)y, mean, rstd, M, D, eps));
+#define PM_LN_FWD(TO, NV) \
+  hipLaunchKernelGGL((ln_fwd_kernel<TO, NV>), dim3(grid), dim3(256), 0, pm_stream(stream), x, ldx, gamma, beta, (TO*)y, mean, rstd, M, D, eps)
+  PM_DISPATCH_ACT(out_dtype, T, {
+    if (D <= 1024) PM_LN_FWD(T, 4); else PM_LN_FWD(T, 5);
+  });
+#undef PM_LN_FWD
   return pm_check_launch();
 }
 
@@ -241,7 +247,7 @@ extern "C" int pm_layernorm_bwd(const void* dy, int dy_dtype, const float* x, lo
                                 long lddx, void* dx_act, int act_dtype, float* dgamma, float* dbeta, float* dcolsum,
                                 int M, int D, void* workspace, size_t ws_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx) return PM_EINVAL;
-  if (M <= 0 || D <= 0 || D > 1024 || (D & 3) || (ldx & 3) || (lddx & 3) || (dres && (lddres & 3))) return PM_ESHAPE;
+  if (M <= 0 || D <= 0 || D > kMaxD || (D & 3) || (ldx & 3) || (lddx & 3) || (dres && (lddres & 3))) return PM_ESHAPE;
   if (dx_act && act_dtype != dy_dtype) return PM_EINVAL;
   int grid = (M + 3) / 4;
   float* partials = nullptr;
@@ -261,7 +267,8 @@ extern "C" int pm_layernorm_bwd(const void* dy, int dy_dtype, const float* x, lo
   hipLaunchKernelGGL((ln_bwd_kernel<TD, TD, NV>), dim3(grid), dim3(256), 0, s, (const TD*)dy, x, ldx, gamma, mean, rstd, \
                      dres, lddres, dx, lddx, (TD*)dx_act, dgamma, dbeta, dcolsum, partials, M, D)
   PM_DISPATCH_ACT(dy_dtype, T, {
-    if (nv == 1) PM_LN_BWD(T, 1); else if (nv == 2) PM_LN_BWD(T, 2); else if (nv == 3) PM_LN_BWD(T, 3); else PM_LN_BWD(T, 4);
+    if (nv == 1) PM_LN_BWD(T, 1); else if (nv == 2) PM_LN_BWD(T, 2); else if (nv == 3) PM_LN_BWD(T, 3);
+    else if (nv == 4) PM_LN_BWD(T, 4); else PM_LN_BWD(T, 5);
   });
 #undef PM_LN_BWD
   if (partials)

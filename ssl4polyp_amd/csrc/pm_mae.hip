@@ -262,19 +262,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ imgs, const float* __restrict__ pred, long ldp,
                                                        int has_cls, const float* __restrict__ mask,
                                                        const float* __restrict__ sums, const float* __restrict__ dloss,
-                                                       T* __restrict__ dpred, int B, int L, int C, int img, int p,
+                                                       T* __restrict__ dpred, long lddp, int B, int L, int C, int img, int p,
                                                        int norm_pix) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int PE = p * p * C, nvec = PE >> 2;
+  const int PE = p * p * C, nvec = PE >> 2, nvec_ld = (int)(lddp >> 2);
   const long rows = (long)B * (L + has_cls);
   const float g0 = dloss[0] / sums[1] * 2.0f / (float)PE;
   for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
     const int b = row / (L + has_cls), t = row % (L + has_cls);
-    T* dr = dpred + row * PE;
+    T* dr = dpred + row * lddp;
     const int l = t - has_cls;
     const float mk = l >= 0 ? mask[(long)b * L + l] : 0.f;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int v = nvec + lane; v < nvec_ld; v += 64) store4<T>(dr + 4 * v, z);  // row padding (lddp > PE: the GEMMs' padded K)
     if (mk == 0.f) {  // kept patch or cls row: no gradient
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       for (int v = lane; v < nvec; v += 64) store4<T>(dr + 4 * v, z);
       continue;
     }
@@ -371,14 +372,15 @@ extern "C" int pm_mae_loss_finish(const float* patch_loss, const float* mask, lo
 }
 
 extern "C" int pm_mae_loss_bwd(const float* imgs, const float* pred, long ldp, int has_cls_row, const float* mask,
-                               const float* sums, const float* dloss, void* dpred, int act_dtype, int B, int C, int img,
-                               int p, int norm_pix, void* stream) {
+                               const float* sums, const float* dloss, void* dpred, long lddp, int act_dtype, int B, int C,
+                               int img, int p, int norm_pix, void* stream) {
   if (!imgs || !pred || !mask || !sums || !dloss || !dpred) return PM_EINVAL;
   if (B <= 0 || C <= 0 || img <= 0 || p <= 0 || (img % p) || ((p * p * C) & 3) || p * p * C > 1024 || (ldp & 3)) return PM_ESHAPE;
+  if (lddp < (long)p * p * C || (lddp & 3)) return PM_ESHAPE;
   const int L = (img / p) * (img / p);
   const int hc = has_cls_row ? 1 : 0;
   const dim3 grid(cap_grid((long)B * (L + hc), 4, 8192));
   PM_DISPATCH_ACT(act_dtype, T, hipLaunchKernelGGL(loss_bwd_kernel<T>, grid, dim3(256), 0, pm_stream(stream), imgs, pred, ldp, hc,
-                                                   mask, sums, dloss, (T*)dpred, B, L, C, img, p, norm_pix));
+                                                   mask, sums, dloss, (T*)dpred, lddp, B, L, C, img, p, norm_pix));
   return pm_check_launch();
 }

@@ -54,20 +54,55 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ imgs, const int* __restrict__ ids_keep,
-                                                     T* __restrict__ cols, int C, int img, int p, int keep) {
+                                                     T* __restrict__ cols, long ldcols, int C, int img, int p, int keep) {
   const int b = blockIdx.x / keep, j = blockIdx.x % keep;
   const int grid = img / p;
   const int pid = ids_keep ? ids_keep[b * keep + j] : j;
   const int gy = pid / grid, gx = pid % grid;
-  const int p4 = p >> 2;
-  const int nvec = C * p * p4;
   const float* src = imgs + (long)b * C * img * img + (long)gy * p * img + gx * p;
-  T* dst = cols + (long)blockIdx.x * C * p * p;
-  for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
-    const int c = v / (p * p4), rem = v % (p * p4);
-    const int py = rem / p4, px = (rem % p4) * 4;
-    const f32x4 val = *reinterpret_cast<const f32x4*>(src + (long)c * img * img + (long)py * img + px);
-    store4<T>(dst + (c * p + py) * p + px, val);
+  T* dst = cols + (long)blockIdx.x * ldcols;
+  const int PE = C * p * p;
+  if ((p & 3) == 0) {  // 16-B reads of a patch row (p = 16: 64 B per row)
+    const int p4 = p >> 2;
+    const int nvec = C * p * p4;
+    for (int v = threadIdx.x; v < nvec; v += blockDim.x) {
+      const int c = v / (p * p4), rem = v % (p * p4);
+      const int py = rem / p4, px = (rem % p4) * 4;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(src + (long)c * img * img + (long)py * img + px);
+      store4<T>(dst + (c * p + py) * p + px, val);
+    }
+  } else {             // p = 14 (ViT-H/14): a patch row starts on an 8-B boundary only; element-wise
+    for (int e = threadIdx.x; e < PE; e += blockDim.x) {
+      const int c = e / (p * p), rem = e % (p * p);
+      const int py = rem / p, px = rem % p;
+      dst[e] = from_f32<T>(src[(long)c * img * img + (long)py * img + px]);
+    }
+  }
+  for (int e = PE + threadIdx.x; e < ldcols; e += blockDim.x) dst[e] = from_f32<T>(0.f);  // row padding (K of the GEMM)
+}
+
+// dst[r][c] = r < rows && c < cols ? src[r][c] : 0 over rows_pad x cols_pad, f32 -> act: a weight whose reduction dimension is not
+// a multiple of the GEMM's k-step (588 = 3 x 14 x 14) laid out as the zero-padded operand the matrix-core kernels take
+template <typename T>
+__global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__ src, long lds, T* __restrict__ dst, long ldd, int rows,
+                                                       int cols, int rows_pad, int cols_pad) {
+  const long total = (long)rows_pad * cols_pad;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = i / cols_pad, c = i % cols_pad;
+    const float v = (r < rows && c < cols) ? src[(long)r * lds + c] : 0.f;
+    dst[(long)r * ldd + c] = from_f32<T>(v);
+  }
+}
+
+// dst[r][c] (+)= src[r][c] over rows x cols: the valid part of a gradient computed in the padded layout
+__global__ __launch_bounds__(256) void unpad_add_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd,
+                                                        int rows, int cols, int accumulate) {
+  const long total = (long)rows * cols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = i / cols, c = i % cols;
+    const float v = src[(long)r * lds + c];
+    float* d = dst + (long)r * ldd + c;
+    *d = accumulate ? *d + v : v;
   }
 }
 
@@ -384,15 +419,37 @@ extern "C" int pm_colsum(const void* x, long ldx, int dtype, float* out, int M, 
   return pm_colsum_ws(x, ldx, dtype, out, M, N, nullptr, 0, stream);
 }
 
-extern "C" int pm_patch_im2col(const float* imgs, const int* ids_keep, void* cols, int out_dtype, int B, int C, int img,
-                               int p, int keep, void* stream) {
+extern "C" int pm_patch_im2col(const float* imgs, const int* ids_keep, void* cols, long ldcols, int out_dtype, int B, int C,
+                               int img, int p, int keep, void* stream) {
   if (!imgs || !cols) return PM_EINVAL;
-  if (B <= 0 || C <= 0 || img <= 0 || p <= 0 || keep <= 0 || (img % p) || (p & 3)) return PM_ESHAPE;
+  if (B <= 0 || C <= 0 || img <= 0 || p <= 0 || keep <= 0 || (img % p)) return PM_ESHAPE;
+  if (ldcols < (long)C * p * p) return PM_ESHAPE;
+  if ((p & 3) == 0 && (ldcols & 3)) return PM_EALIGN;  // (vector stores)
   const int L = (img / p) * (img / p);
   if (keep > L || (!ids_keep && keep != L)) return PM_ESHAPE;
   const dim3 grid(B * keep);
   PM_DISPATCH_ACT(out_dtype, T, hipLaunchKernelGGL(im2col_kernel<T>, grid, dim3(256), 0, pm_stream(stream), imgs, ids_keep, (T*)cols,
-                                                   C, img, p, keep));
+                                                   ldcols, C, img, p, keep));
+  return pm_check_launch();
+}
+
+extern "C" int pm_pad_cast(const float* src, long lds, void* dst, long ldd, int dst_dtype, int rows, int cols, int rows_pad,
+                           int cols_pad, void* stream) {
+  if (!src || !dst) return PM_EINVAL;
+  if (rows <= 0 || cols <= 0 || rows_pad < rows || cols_pad < cols || lds < cols || ldd < cols_pad) return PM_ESHAPE;
+  const long total = (long)rows_pad * cols_pad;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  PM_DISPATCH_ACT(dst_dtype, T, hipLaunchKernelGGL(pad_cast_kernel<T>, dim3(grid), dim3(256), 0, pm_stream(stream), src, lds, (T*)dst,
+                                                   ldd, rows, cols, rows_pad, cols_pad));
+  return pm_check_launch();
+}
+
+extern "C" int pm_unpad_add(const float* src, long lds, float* dst, long ldd, int rows, int cols, int accumulate, void* stream) {
+  if (!src || !dst) return PM_EINVAL;
+  if (rows <= 0 || cols <= 0 || lds < cols || ldd < cols) return PM_ESHAPE;
+  const long total = (long)rows * cols;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(unpad_add_kernel, dim3(grid), dim3(256), 0, pm_stream(stream), src, lds, dst, ldd, rows, cols, accumulate ? 1 : 0);
   return pm_check_launch();
 }
 
@@ -516,7 +573,7 @@ extern "C" const char* pm_strerror(int status) {
 
 // 3: pm_gemm_ex / pm_gemm_opts replace pm_tune, workspace queries, pm_vit_head_*, pm_supervised_loss_fwd, pm_scale
 // 10: PM_F16 (precision mode fp16), pm_loss_scale_update, pm_dgelu
-extern "C" int pm_abi_version(void) { return 10; }
+extern "C" int pm_abi_version(void) { return 11; }
 
 extern "C" size_t pm_workspace_bytes(int kind, int M, int N) {
   if (M <= 0 || N <= 0) return 0;

@@ -319,6 +319,26 @@ class Kernels:
     def cast(self, src, dst):
         _lib.check(self.lib.pm_cast(_ptr(src), _ptr(dst), _lib.dtype_code(dst.dtype), src.numel(), _stream()), "pm_cast")
 
+    # A Linear whose reduction dimension is not a multiple of the GEMM k-step (patch 14: 3 * 14 * 14 = 588) runs in a layout
+    # padded with zeros to the next multiple of 64: operands by pad_cast, the valid part of a gradient back by unpad_add.
+    @staticmethod
+    def padded_k(K: int) -> int:
+        return K if K % 64 == 0 else (K + 63) // 64 * 64
+
+    def pad_cast(self, src: torch.Tensor, rows_pad: int, cols_pad: int) -> torch.Tensor:
+        """f32 [rows, cols] -> act [rows_pad, cols_pad], zeros outside the source."""
+        rows, cols = src.shape
+        dst = torch.empty(rows_pad, cols_pad, dtype=self.act_dtype, device=src.device)
+        _lib.check(self.lib.pm_pad_cast(_ptr(src), cols, _ptr(dst), cols_pad, self.act, rows, cols, rows_pad, cols_pad, _stream()),
+                   "pm_pad_cast")
+        return dst
+
+    def unpad_add(self, src: torch.Tensor, dst: torch.Tensor, accumulate: bool) -> None:
+        """dst f32 [rows, cols] (+)= src f32 [>= rows, >= cols][:rows, :cols]."""
+        rows, cols = dst.shape
+        _lib.check(self.lib.pm_unpad_add(_ptr(src), src.shape[1], _ptr(dst), cols, rows, cols, 1 if accumulate else 0, _stream()),
+                   "pm_unpad_add")
+
 
 @dataclass
 class StackGeom:

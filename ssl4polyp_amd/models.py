@@ -213,13 +213,17 @@ class _EncoderFrontMixin:
         p = mod.patch_embed.patch_size[0]
         D = rt.enc_geom.dim
         PE = C * p * p
+        PEp = k.padded_k(PE)  # (patch 14: 588 -> 640, zero columns in both operands)
         dev = imgs.device
-        cols = torch.empty(B * keep, PE, dtype=k.act_dtype, device=dev)
-        _lib.check(k.lib.pm_patch_im2col(_ptr(imgs), _ptr(ids_keep), _ptr(cols), k.act, B, C, img, p, keep, _stream()),
+        cols = torch.empty(B * keep, PEp, dtype=k.act_dtype, device=dev)
+        _lib.check(k.lib.pm_patch_im2col(_ptr(imgs), _ptr(ids_keep), _ptr(cols), PEp, k.act, B, C, img, p, keep, _stream()),
                    "pm_patch_im2col")
         emb = torch.empty(B * keep, D, dtype=torch.float32, device=dev)
-        k.linear_fwd(cols, f.shadow_view("patch_embed.proj.weight").view(D, PE), f.param_view("patch_embed.proj.bias"),
-                     emb, B * keep, D, PE)
+        if PEp == PE:
+            w = f.shadow_view("patch_embed.proj.weight").view(D, PE)
+        else:
+            w = k.pad_cast(f.param_view("patch_embed.proj.weight").view(D, PE), D, PEp)
+        k.linear_fwd(cols, w, f.param_view("patch_embed.proj.bias"), emb, B * keep, D, PEp)
         x0 = torch.empty(B * (keep + 1), D, dtype=torch.float32, device=dev)
         _lib.check(k.lib.pm_assemble_tokens(_ptr(emb), _ptr(f.param_view("cls_token")), _ptr(f.param_view(pos_name)),
                                             _ptr(ids_keep), _ptr(x0), B, keep, D, _stream()), "pm_assemble_tokens")
@@ -229,7 +233,8 @@ class _EncoderFrontMixin:
     def front_bwd(rt: _Runtime, dx0, cols, ids_keep, B, keep, accumulate, need, learn_pos):
         k, f = rt.k, rt.flat
         D = rt.enc_geom.dim
-        PE = cols.shape[1]
+        PEp = cols.shape[1]
+        PE = f.param_view("patch_embed.proj.weight").numel() // D
         demb = torch.empty(B * keep, D, dtype=k.act_dtype, device=cols.device)
         dcls = f.grad_view("cls_token") if need("cls_token") else None
         dpos = f.grad_view("pos_embed") if learn_pos and need("pos_embed") else None
@@ -244,8 +249,13 @@ class _EncoderFrontMixin:
                                                     keep, D, _stream()), "pm_assemble_tokens_bwd")
         if need("patch_embed.proj.weight"):
             # (its own split-K scratch: the last blocks' weight gradients may still be running on the side stream)
-            k.linear_wgrad(demb, cols, f.grad_view("patch_embed.proj.weight").view(D, PE), B * keep, D, PE, accumulate,
-                           ws_name="_ws_front")
+            if PEp == PE:
+                k.linear_wgrad(demb, cols, f.grad_view("patch_embed.proj.weight").view(D, PE), B * keep, D, PE, accumulate,
+                               ws_name="_ws_front")
+            else:  # the gradient in the padded layout, its valid columns into the parameter's gradient
+                dw = torch.empty(D, PEp, dtype=torch.float32, device=cols.device)
+                k.linear_wgrad(demb, cols, dw, B * keep, D, PEp, False, ws_name="_ws_front")
+                k.unpad_add(dw, f.grad_view("patch_embed.proj.weight").view(D, PE), accumulate)
         if need("patch_embed.proj.bias"):
             k.colsum(demb, f.grad_view("patch_embed.proj.bias"), B * keep, D)
 
@@ -500,14 +510,27 @@ class _MaeFn(torch.autograd.Function):
             dloss = torch.zeros((), dtype=torch.float32, device=dev)
         dloss = dloss.reshape(1).contiguous().float()
         # -- loss + decoder_pred
-        dpred_act = torch.empty(Md, PE, dtype=k.act_dtype, device=dev)
+        PEp = k.padded_k(PE)  # (patch 14: the 588 outputs of decoder_pred are the reduction dimension of its backward GEMMs)
+        dpred_act = torch.empty(Md, PEp, dtype=k.act_dtype, device=dev)
         _lib.check(k.lib.pm_mae_loss_bwd(_ptr(imgs), _ptr(pred_full), PE, 1, _ptr(mask), _ptr(sums), _ptr(dloss),
-                                         _ptr(dpred_act), k.act, B, C, img, p, npx, _stream()), "pm_mae_loss_bwd")
-        if need("decoder_pred.weight"):
-            k.linear_wgrad(dpred_act, yn, f.grad_view("decoder_pred.weight"), Md, PE, Dd, accumulate)
-        if need("decoder_pred.bias"):
-            k.colsum(dpred_act, f.grad_view("decoder_pred.bias"), Md, PE)
-        k.linear_dgrad(dpred_act, f.shadow_view("decoder_pred.weight"), ws_d.d_ln, Md, PE, Dd)
+                                         _ptr(dpred_act), PEp, k.act, B, C, img, p, npx, _stream()), "pm_mae_loss_bwd")
+        if PEp == PE:
+            if need("decoder_pred.weight"):
+                k.linear_wgrad(dpred_act, yn, f.grad_view("decoder_pred.weight"), Md, PE, Dd, accumulate)
+            if need("decoder_pred.bias"):
+                k.colsum(dpred_act, f.grad_view("decoder_pred.bias"), Md, PE)
+            k.linear_dgrad(dpred_act, f.shadow_view("decoder_pred.weight"), ws_d.d_ln, Md, PE, Dd)
+        else:
+            if need("decoder_pred.weight"):
+                dw = torch.empty(PEp, Dd, dtype=torch.float32, device=dev)
+                k.linear_wgrad(dpred_act, yn, dw, Md, PEp, Dd, False)
+                k.unpad_add(dw, f.grad_view("decoder_pred.weight").view(PE, Dd), accumulate)
+            if need("decoder_pred.bias"):
+                db = torch.zeros(1, PEp, dtype=torch.float32, device=dev)
+                k.colsum(dpred_act, db, Md, PEp)
+                k.unpad_add(db, f.grad_view("decoder_pred.bias").view(1, PE), True)  # (vector gradients always accumulate)
+            wpad = k.pad_cast(f.param_view("decoder_pred.weight").view(PE, Dd), PEp, Dd)
+            k.linear_dgrad(dpred_act, wpad, ws_d.d_ln, Md, PEp, Dd)
         Wd, Gd = rt.stack_weights("decoder_blocks.", gd.depth)
         tr_d = [any(need(f"decoder_blocks.{i}.{n}") for n in BLOCK_PARAM_NAMES) for i in range(gd.depth)]
         last = gd.depth - 1
@@ -687,14 +710,13 @@ def mae_vit_large_patch16_dec512d8b(**kwargs):
 
 
 def mae_vit_huge_patch14_dec512d8b(**kwargs):
-    """models_mae.py:239-244.  Not runnable on the HIP path: ViT-H has 16 heads of 80 (the attention kernels tile dh = 32 / 64:
-    80 is neither a whole number of 32-wide output tiles nor a power-of-two LDS row), the row-in-registers LayerNorm kernels
-    stop at D = 1024 (ViT-H is 1280), and a 14x14 patch gives a 588-element im2col row, which is not a multiple of the 16-byte
-    chunks the 16-bit GEMM loads.  No shipped config of the reference uses it (run_hyperkvasir_pretraining.py:96 fixes
-    mae_vit_base_patch16), so the factory fails at construction instead of at the first forward."""
-    raise NotImplementedError("mae_vit_huge_patch14 is outside the MI355X hot path (attention kernels: head dim 32 / 64, ViT-H "
-                              "has 80; LayerNorm kernels: D <= 1024; patch 14 -> K = 588 is not 16-byte aligned); use the base "
-                              "or large factory")
+    """models_mae.py:239-244: ViT-H/14 -- D = 1280, 32 blocks, 16 heads of 80, 256 + 1 tokens at 224^2, a 588-element patch.
+    What differs from the base path: 80-wide heads run the attention kernels on LDS rows padded to 128 (3 feature tiles, the
+    last half empty), N = 257 takes nine 32-row tiles, LayerNorm keeps 5 float4 per lane, and the two Linears whose reduction
+    dimension is 588 (PatchEmbed.proj forward / weight gradient, decoder_pred backward) run zero-padded to 640."""
+    return MaskedAutoencoderViT(patch_size=14, embed_dim=1280, depth=32, num_heads=16, decoder_embed_dim=512,
+                                decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                                norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
 
 
 mae_vit_base_patch16 = mae_vit_base_patch16_dec512d8b

@@ -43,7 +43,7 @@ def _need_gpu():
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,D", [(37, 768), (50, 512), (13, 64), (7, 32), (2000, 768)])
+@pytest.mark.parametrize("M,D", [(37, 768), (50, 512), (13, 64), (7, 32), (2000, 768), (41, 1024), (130, 1280)])
 @pytest.mark.parametrize("prec", PRECS)
 def test_layernorm_fwd_bwd(M, D, prec):
     k = _k(prec)
@@ -251,7 +251,13 @@ def _attn_ref(qkv, B, N, H, dh):
 
 
 @pytest.mark.parametrize("B,N,H,dh", [(2, 197, 3, 64), (3, 50, 2, 64), (2, 197, 4, 32), (2, 17, 2, 32), (1, 33, 1, 64),
-                                      (1, 224, 1, 32)])
+                                      (1, 224, 1, 32),
+                                      # ViT-H/14 (models_mae.py:239-244): 80-wide heads at N = 65 (masked) / 257, the decoder's
+                                      # 32-wide heads and a 64-wide head at N = 257, and the shapes in between
+                                      (2, 65, 3, 80), (2, 257, 2, 80), (1, 197, 2, 80), (2, 257, 4, 32), (1, 257, 2, 64),
+                                      (1, 288, 1, 80), (1, 3, 1, 80),
+                                      # more than one tile of padding (N = 100 runs the seven-tile instantiation)
+                                      (2, 100, 2, 64), (1, 130, 2, 32), (1, 70, 1, 64)])
 @pytest.mark.parametrize("prec", PRECS)
 def test_attention_fwd_bwd(B, N, H, dh, prec):
     k = _k(prec)
@@ -358,7 +364,7 @@ def test_colsum_cast_gradstats(prec):
     assert abs(stats[0].item() - (g2.double() ** 2).sum().item()) < 1e-3 * stats[0].item()
 
 
-@pytest.mark.parametrize("img,p,D", [(224, 16, 768), (32, 8, 64)])
+@pytest.mark.parametrize("img,p,D", [(224, 16, 768), (32, 8, 64), (56, 14, 128)])
 @pytest.mark.parametrize("prec", PRECS)
 def test_patch_embed_path(img, p, D, prec):
     """im2col (+kept-patch gather) + GEMM + token assembly == Conv2d patch embed + pos + cls (+ gather)."""
@@ -375,11 +381,21 @@ def test_patch_embed_path(img, p, D, prec):
     ref = ref + pos[1:]
     g = torch.Generator().manual_seed(65)
     ids = torch.stack([torch.randperm(L, generator=g)[:keep] for _ in range(B)]).to(DEV)
+    PE = C * p * p
+    PEp = k.padded_k(PE)  # patch 14: 588 -> 640, zero columns in the patch rows and in the weight
+    assert (PEp == PE) == (p != 14)
     for ids_keep, kp in ((None, L), (ids.int().contiguous(), keep)):
-        cols = torch.empty(B * kp, C * p * p, dtype=k.act_dtype, device=DEV)
-        _lib.check(k.lib.pm_patch_im2col(_ptr(imgs), _ptr(ids_keep), _ptr(cols), k.act, B, C, img, p, kp, _stream()), "im2col")
+        cols = torch.full((B * kp, PEp), float("nan"), dtype=k.act_dtype, device=DEV)
+        _lib.check(k.lib.pm_patch_im2col(_ptr(imgs), _ptr(ids_keep), _ptr(cols), PEp, k.act, B, C, img, p, kp, _stream()), "im2col")
+        assert torch.equal(cols[:, PE:], torch.zeros(B * kp, PEp - PE, dtype=k.act_dtype, device=DEV))
         emb = torch.empty(B * kp, D, device=DEV)
-        k.linear_fwd(cols, W.to(k.act_dtype).view(D, -1), bias, emb, B * kp, D, C * p * p)
+        w = W.to(k.act_dtype).view(D, -1) if PEp == PE else k.pad_cast(W.view(D, PE).contiguous(), D, PEp)
+        if PEp != PE:
+            assert torch.equal(w[:, :PE], W.to(k.act_dtype).view(D, PE)) and not w[:, PE:].any()
+            back = torch.ones(D, PE, device=DEV)
+            k.unpad_add(w.float().contiguous(), back, True)
+            assert torch.equal(back, 1 + W.to(k.act_dtype).view(D, PE).float())
+        k.linear_fwd(cols, w, bias, emb, B * kp, D, PEp)
         x = torch.empty(B, kp + 1, D, device=DEV)
         _lib.check(k.lib.pm_assemble_tokens(_ptr(emb), _ptr(cls), _ptr(pos), _ptr(ids_keep), _ptr(x), B, kp, D, _stream()), "assemble")
         want = ref if ids_keep is None else torch.gather(ref, 1, ids.unsqueeze(-1).expand(-1, -1, D))
@@ -440,7 +456,7 @@ def test_mae_masking_and_unshuffle():
 
 
 @pytest.mark.parametrize("norm_pix", [0, 1])
-@pytest.mark.parametrize("img,p", [(224, 16), (32, 8)])
+@pytest.mark.parametrize("img,p", [(224, 16), (32, 8), (56, 14)])
 def test_mae_loss(norm_pix, img, p):
     from oracle import vit_mae_ref as O
     from ssl4polyp_amd import _lib
@@ -460,12 +476,14 @@ def test_mae_loss(norm_pix, img, p):
     want = O.mae_loss(imgs.cpu(), pr, mask.cpu(), cfg, bool(norm_pix))
     assert abs(loss.item() - want.item()) < 2e-6 * abs(want.item())
     want.backward()
-    dpred = torch.full((B, L + 1, PE), float("nan"), device=DEV)
+    PEp = k.padded_k(PE)  # (row pitch of dpred: the reduction dimension of decoder_pred's backward GEMMs)
+    dpred = torch.full((B, L + 1, PEp), float("nan"), device=DEV)
     dl = torch.full((1,), 0.5, device=DEV)
-    _lib.check(k.lib.pm_mae_loss_bwd(_ptr(imgs), _ptr(pred_full), PE, 1, _ptr(mask), _ptr(sums), _ptr(dl), _ptr(dpred), 0, B, C,
+    _lib.check(k.lib.pm_mae_loss_bwd(_ptr(imgs), _ptr(pred_full), PE, 1, _ptr(mask), _ptr(sums), _ptr(dl), _ptr(dpred), PEp, 0, B, C,
                                      img, p, norm_pix, _stream()), "loss_bwd")
-    assert torch.equal(dpred[:, 0], torch.zeros(B, PE, device=DEV))
-    assert rel(dpred[:, 1:], 0.5 * pr.grad) < 1e-5
+    assert torch.equal(dpred[:, 0], torch.zeros(B, PEp, device=DEV))
+    assert not dpred[:, :, PE:].any()
+    assert rel(dpred[:, 1:, :PE], 0.5 * pr.grad) < 1e-5
 
 
 def test_cls_head_and_adamw():

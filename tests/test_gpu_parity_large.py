@@ -527,8 +527,7 @@ def test_finetune_mode_full_trains_the_positional_table_like_the_reference():
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_mae_vit_large_factory_vs_oracle(prec):
     """`mae_vit_large_patch16` (models_mae.py:231-236: D = 1024, 24 blocks, 16 heads -- the widest row the LayerNorm kernels hold in
-    registers, a 1024 x 4096 MLP) forward + backward at B = 3 against the oracle with ViT-L geometry.  (ViT-H is not on the HIP
-    path: dh = 80 heads, D = 1280, 14 x 14 patches -- the factory raises at construction; INTEGRATION.md.)"""
+    registers at four float4 per lane, a 1024 x 4096 MLP) forward + backward at B = 3 against the oracle with ViT-L geometry."""
     import ssl4polyp_amd as A
     from oracle import vit_mae_ref as O
     cfg = O.ViTConfig(embed_dim=1024, depth=24, num_heads=16)
@@ -551,3 +550,95 @@ def test_mae_vit_large_factory_vs_oracle(prec):
     print(f"[parity] mae ViT-L B={B} {prec}: loss rel {e_loss:.3e}, pred rel-L2 {e_pred:.3e}, worst gradient rel-L2 {worst[0]:.3e} ({worst[1]})")
     t = TOL[prec]
     assert e_loss < t["loss"] and e_pred < t["pred"] and worst[0] < (1e-3 if prec == "fp32" else 1.5e-2)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+def test_vit_huge_geometry_two_blocks_vs_oracle(prec):
+    """The shapes of `mae_vit_huge_patch14` (models_mae.py:239-244) that differ in kind from ViT-B/16 -- D = 1280 (five float4 per
+    lane in LayerNorm), 16 heads of 80 (LDS rows padded to 128, three feature tiles), 256 + 1 tokens (nine 32-row tiles; 65 under
+    masking), a 588-element patch (PatchEmbed.proj and decoder_pred run zero-padded to 640) -- at depth 2 + 1 so that the oracle
+    takes seconds: loss, pred and EVERY parameter gradient."""
+    import ssl4polyp_amd as A
+    from oracle import vit_mae_ref as O
+    from functools import partial
+    cfg = O.ViTConfig(patch_size=14, embed_dim=1280, depth=2, num_heads=16, decoder_depth=1)
+    B = 3
+    sd = O.generated_state_dict(cfg, 71, decoder=True, n_class=None)
+    imgs, _, noise = O.generated_batch(cfg, B, 72)
+    _threads()
+    leaves = {n: v.clone().requires_grad_("pos_embed" not in n) for n, v in sd.items()}
+    loss_ref, pred_ref, mask_ref = O.mae_forward(leaves, imgs, noise, cfg)
+    loss_ref.backward()
+    m = A.MaskedAutoencoderViT(patch_size=14, embed_dim=1280, depth=2, num_heads=16, decoder_embed_dim=512, decoder_depth=1,
+                               decoder_num_heads=16, mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), precision=prec)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    scale = LOSS_SCALE if prec == "fp16" else 1.0
+    loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    (loss * scale).backward()
+    assert torch.equal(mask.cpu(), mask_ref)
+    assert pred.shape == (B, 256, 588)
+    e_loss, e_pred = rel(loss, loss_ref.detach()), rel_l2(pred, pred_ref.detach())
+    worst = max((rel_l2(p.grad / scale, leaves[n].grad), n) for n, p in m.named_parameters()
+                if p.grad is not None and not n.endswith("attn.qkv.bias"))
+    print(f"[parity] ViT-H geometry (2 + 1 blocks) B={B} {prec}: loss rel {e_loss:.3e}, pred rel-L2 {e_pred:.3e}, "
+          f"worst gradient rel-L2 {worst[0]:.3e} ({worst[1]})")
+    t = TOL[prec]
+    assert e_loss < t["loss"] and e_pred < t["pred"] and worst[0] < (1e-4 if prec == "fp32" else 1e-2)
+    # a second step accumulates into the same gradients (the padded-layout gradients are ADDED to the running ones)
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    loss2, _, _ = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+    (loss2 * scale).backward()
+    for n in ("patch_embed.proj.weight", "decoder_pred.weight", "decoder_pred.bias", "blocks.1.mlp.fc1.weight"):
+        assert rel_l2(dict(m.named_parameters())[n].grad, 2 * g1[n]) < 1e-6, n
+
+
+def test_mae_vit_huge_factory_vs_reference_fixture(golden):
+    """`mae_vit_huge_patch14` itself (32 blocks, 632 M parameters), forward + backward at B = 4 in the three precision modes against
+    what the REFERENCE produced for the same PCG64 weights and batch (tests/golden/make_mae_huge_grads.py ran
+    models_mae.mae_vit_huge_patch14 in the build container): loss, mask, slices and per-sample sums of pred, the norm of every
+    parameter gradient, whole vector gradients, first and LAST 32 x 32 corners of weight-matrix gradients (the last rows / columns
+    of the 588-wide matrices sit next to the zero padding of the HIP path)."""
+    import ssl4polyp_amd as A
+    import numpy as np
+    from oracle import vit_mae_ref as O
+    fx = golden("vith_mae_grads.npz")
+    B = int(fx["batch"])
+    cfg = O.VIT_HUGE
+    sd = O.generated_state_dict(cfg, int(fx["weight_seed"]), decoder=True, n_class=None)
+    imgs, _, noise = O.generated_batch(cfg, B, int(fx["batch_seed"]))
+    res = {}
+    for prec in ("fp32", "bf16", "fp16"):
+        m = A.mae_vit_huge_patch14(norm_pix_loss=False, precision=prec)
+        m.load_state_dict(sd)
+        m.to(DEV)
+        loss, pred, mask = m(imgs.to(DEV), mask_ratio=0.75, noise=noise.to(DEV))
+        scale = LOSS_SCALE if prec == "fp16" else 1.0
+        (loss * scale).backward()
+        assert np.array_equal(mask.cpu().numpy().astype(np.uint8), fx["mask"])
+        params = dict(m.named_parameters())
+        for p_ in params.values():
+            if p_.grad is not None and scale != 1.0:
+                p_.grad.div_(scale)
+        e_loss = abs(float(loss) - float(fx["loss"])) / abs(float(fx["loss"]))
+        e_pred = max(rel_l2(pred[:, :8, :40], fx["pred_slice"]), rel_l2(pred[:, -4:, -24:], fx["pred_tail_slice"]),
+                     rel_l2(pred.abs().double().sum(dim=(1, 2)), fx["pred_abs_sum_per_sample"]),
+                     abs(float(pred.double().norm()) - float(fx["pred_norm"])) / float(fx["pred_norm"]))
+        norms = {n: float(params[n].grad.double().norm()) for n in fx["grad_names"]}
+        e_norm = {n: abs(norms[n] - w) / w for n, w in zip(fx["grad_names"], fx["grad_norms"]) if not n.endswith("attn.qkv.bias")}
+        e_full = {key[2:]: rel_l2(params[key[2:]].grad, fx[key]) for key in fx
+                  if key.startswith("g/") and not key.endswith("attn.qkv.bias")}
+        flat2 = lambda n: params[n].grad.reshape(params[n].shape[0], -1)
+        e_corner = {key[9:]: rel_l2(flat2(key[9:])[:32, :32], fx[key]) for key in fx if key.startswith("g_corner/")}
+        e_corner.update({key[14:] + " (last)": rel_l2(flat2(key[14:])[-32:, -32:], fx[key]) for key in fx
+                         if key.startswith("g_corner_last/")})
+        wn, wf, wc = max(e_norm, key=e_norm.get), max(e_full, key=e_full.get), max(e_corner, key=e_corner.get)
+        print(f"[parity] mae ViT-H/14 B={B} {prec} vs reference fixture: loss rel {e_loss:.3e}; pred {e_pred:.3e}; gradient norms worst "
+              f"{e_norm[wn]:.3e} ({wn}); vector gradients rel-L2 worst {e_full[wf]:.3e} ({wf}); matrix corners rel-L2 worst "
+              f"{e_corner[wc]:.3e} ({wc})")
+        res[prec] = (e_loss, e_pred, e_norm[wn], e_full[wf], e_corner[wc])
+        del m, params
+        torch.cuda.empty_cache()
+    assert res["fp32"][0] < 1e-5 and max(res["fp32"][1:]) < 1e-3, res["fp32"]
+    for prec in ("bf16", "fp16"):
+        assert res[prec][0] < 1e-3 and max(res[prec][1:]) < 2e-2, (prec, res[prec])

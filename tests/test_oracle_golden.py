@@ -74,6 +74,41 @@ def test_tiny_classifiers(golden):
 
 
 @pytest.mark.timeout(600)
+def test_vith_mae_generated_weights(golden):
+    """The oracle at the geometry of `mae_vit_huge_patch14` (models_mae.py:239-244: patch 14, D = 1280, 32 blocks, 16 heads of 80)
+    against what the reference itself produced (tests/golden/make_mae_huge_grads.py): this pins the checker of the ViT-H GPU tests."""
+    fx = golden("vith_mae_grads.npz")
+    cfg = O.VIT_HUGE
+    torch.set_num_threads(len(os.sched_getaffinity(0)))
+    sd = O.generated_state_dict(cfg, int(fx["weight_seed"]), decoder=True, n_class=None)
+    imgs, _, noise = O.generated_batch(cfg, int(fx["batch"]), int(fx["batch_seed"]))
+    names = [str(n) for n in fx["grad_names"]]
+    leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
+    sd2 = dict(sd)
+    sd2.update(leaves)
+    loss, pred, mask = O.mae_forward(sd2, imgs, noise, cfg)
+    loss.backward()
+    assert pred.shape == (int(fx["batch"]), 256, 588)
+    np.testing.assert_array_equal(mask.numpy().astype(np.uint8), fx["mask"])
+    np.testing.assert_allclose(loss.item(), fx["loss"], rtol=2e-6)
+    pred = pred.detach()
+    np.testing.assert_allclose(pred[:, :8, :40].numpy(), fx["pred_slice"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(pred[:, -4:, -24:].numpy(), fx["pred_tail_slice"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(pred.abs().double().sum(dim=(1, 2)).numpy(), fx["pred_abs_sum_per_sample"], rtol=1e-5)
+    norms = np.array([leaves[n].grad.double().norm().item() for n in names])
+    np.testing.assert_allclose(norms, fx["grad_norms"], rtol=5e-4)
+    for k in fx:
+        if k.startswith("g/"):
+            ref = fx[k]
+            np.testing.assert_allclose(leaves[k[2:]].grad.numpy(), ref, rtol=0, atol=1e-7 + 2e-4 * np.abs(ref).max(), err_msg=k)
+        elif k.startswith("g_corner/") or k.startswith("g_corner_last/"):
+            n = k.split("/", 1)[1]
+            g = leaves[n].grad.reshape(leaves[n].shape[0], -1)
+            got = g[:32, :32] if k.startswith("g_corner/") else g[-32:, -32:]
+            np.testing.assert_allclose(got.numpy(), fx[k], rtol=0, atol=1e-7 + 2e-4 * np.abs(fx[k]).max(), err_msg=k)
+
+
+@pytest.mark.timeout(600)
 def test_vitb_mae_generated_weights(golden):
     fx = golden("vitb_mae.npz")
     cfg = O.VIT_BASE
