@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-kernel-stats", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle parity block (CPU time)")
     ap.add_argument("--no-mae", action="store_true", help="cls headline only (no MAE sub-records)")
+    ap.add_argument("--no-vith", action="store_true", help="no mae_vit_huge_patch14 sub-record")
     ap.add_argument("--no-fp16", action="store_true", help="skip the precision-mode fp16 sub-records (cls bs=64, MAE bs=256)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the short fp32-mode (exact-f32 MFMA) cls record")
     ap.add_argument("--single-batch", action="store_true",
@@ -98,7 +99,20 @@ def parse():
     return ap.parse_args()
 
 
-def build(workload, precision, device, world, batch, finetune_mode="full", force_sync=False):
+def mae_gflop_per_img(m, mask_ratio=0.75):
+    """Algorithmic GFLOP per image per MAE training step of any factory (contractions only, step = 3 x forward -- BASELINE.md section 3's
+    convention; gives 58.16 for mae_vit_base_patch16): patch embedding on the kept patches, 12 D^2 + 2 N D MACs per token and block."""
+    pe = m.patch_embed
+    L, p = pe.num_patches, pe.patch_size[0]
+    keep = int(L * (1 - mask_ratio))
+    De, Dd = m.cls_token.shape[-1], m.mask_token.shape[-1]
+    stack = lambda D, N, depth: depth * N * (12 * D * D + 2 * N * D)
+    macs = keep * 3 * p * p * De + stack(De, keep + 1, len(m.blocks)) + (keep + 1) * De * Dd + \
+        stack(Dd, L + 1, len(m.decoder_blocks)) + (L + 1) * Dd * 3 * p * p
+    return 3 * 2 * macs / 1e9
+
+
+def build(workload, precision, device, world, batch, finetune_mode="full", force_sync=False, factory=None):
     import ssl4polyp_amd as A
     from ssl4polyp_amd.optim import FusedAdamW, LossScaler, add_weight_decay
     from ssl4polyp_amd.parallel import DataParallel
@@ -110,7 +124,8 @@ def build(workload, precision, device, world, batch, finetune_mode="full", force
         # EVERY parameter trainable (the sincos pos_embed too), the other modes freeze everything but lin_head (+ tail blocks)
         configure_finetune_parameters(model, finetune_mode)
     else:
-        model = A.mae_vit_base_patch16(norm_pix_loss=False, precision=precision)
+        # factory: another of models_mae.py:223-250's factories (mae_vit_large_patch16, mae_vit_huge_patch14) as a sub-record
+        model = getattr(A, factory or "mae_vit_base_patch16")(norm_pix_loss=False, precision=precision)
     ddp = DataParallel(model, device, force_sync=force_sync)
     if workload == "cls":
         # tc.py:5751-5768: AdamW(lr 1e-3, wd 0.05) over two groups head / backbone (config/base.yaml:1-4), built from ALL
@@ -733,12 +748,18 @@ def dist_config(world, rank, local, device_name, sync_info, backend):
 
 # ---------------------------------------------------------------------------------------------------------------------
 def run_workload(args, workload, batch, device, world, rank, headline, finetune_mode="full", light=False, precision=None,
-                 kstats=True, eval_forward=None):
+                 kstats=True, eval_forward=None, factory=None):
     """Build, warm up, time exactly args.steps steps (barrier + synchronize on both sides, max over ranks).
+    factory: an MAE factory other than the base one (no parity block: the cached oracle run is ViT-B's; parity of the larger
+    factories is tests/test_gpu_parity_large.py's, against fixtures made by the reference).
     light: a C5 sub-record -- no kernel statistics, parity against the cached oracle run of the headline, + eval forward.
     precision: this record's precision mode (default: --precision); kstats: per-kernel HIP-event statistics."""
     args = argparse.Namespace(**{**vars(args), "precision": precision or args.precision})
-    model, ddp, opt = build(workload, args.precision, device, world, batch, finetune_mode, force_sync=args.force_sync and world == 1)
+    if factory:
+        args = argparse.Namespace(**{**vars(args), "no_parity": True})
+        kstats = False
+    model, ddp, opt = build(workload, args.precision, device, world, batch, finetune_mode, force_sync=args.force_sync and world == 1,
+                            factory=factory)
     imgs, labels = make_batch(workload, batch, device, rank, pool=not args.single_batch)
     pooled = isinstance(imgs, list)
     imgs0, labels0 = (imgs[0], labels[0]) if pooled else (imgs, labels)   # the batch of the parity block / the eval forward
@@ -939,11 +960,12 @@ def run_workload(args, workload, batch, device, world, rank, headline, finetune_
         model.train()
     if rank == 0:
         ips = batch * world * args.steps / dt
-        gflop = FINETUNE_GFLOP[finetune_mode] if workload == "cls" else GFLOP_PER_IMG[workload]
+        gflop = FINETUNE_GFLOP[finetune_mode] if workload == "cls" else \
+            (round(mae_gflop_per_img(model), 2) if factory else GFLOP_PER_IMG[workload])
         per_gpu_tflops = ips / world * gflop / 1e3
         peak = PEAK_TFLOPS[args.precision]
         roof = {"bound": "mfma", "achieved": round(per_gpu_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(per_gpu_tflops / peak, 4), "traffic": None,
+                "frac": round(per_gpu_tflops / peak, 4), "traffic": None, "gflop_per_img": gflop,
                 "basis": f"{gflop} algorithmic GFLOP/img/step x img/s/GPU (BASELINE.md §3)"}
         if stats is not None:
             ks, hb, at, gt = stats
@@ -1215,6 +1237,11 @@ def main():
         subs["mae_bs64"] = run_workload(args, "mae", 64, device, world, rank, False, kstats=False)
         if not args.no_fp16:
             subs["mae_bs256_fp16"] = run_workload(args, "mae", 256, device, world, rank, False, precision="fp16", kstats=False)
+        if not args.no_vith:
+            # the largest factory of the row-#1 file (models_mae.py:239-244: ViT-H/14, 632 M parameters) at the metric's batch: a short
+            # record (its steps are ~10x a ViT-B step's)
+            ah = argparse.Namespace(**{**vars(args), "steps": min(args.steps, 12), "warmup": min(args.warmup, 3), "preheat": 0.5})
+            subs["mae_vith14_bs64"] = run_workload(ah, "mae", 64, device, world, rank, False, kstats=False, factory="mae_vit_huge_patch14")
     c5 = None
     if default_line and args.finetune_mode == "full" and not args.no_c5 and args.graph != "on":
         # configs[4] (C5): the staged fine-tune regimes of finetune.py:49-91 on the same synthetic step, + the eval forward
@@ -1278,6 +1305,9 @@ def main():
         flat("mae_bs256", subs.get("mae_bs256"), ("loss_rel", "pred_rel_l2"))
         flat("mae_bs64", subs.get("mae_bs64"), ("loss_rel", "pred_rel_l2"))
         flat("mae_bs256_fp16", subs.get("mae_bs256_fp16"), ("loss_rel", "pred_rel_l2"))
+        flat("mae_vith14_bs64", subs.get("mae_vith14_bs64"))
+        if subs.get("mae_vith14_bs64"):
+            cfg["mae_vith14_bs64_gflop_per_img"] = subs["mae_vith14_bs64"]["roofline"].get("gflop_per_img")
         for m, r in (c5 or {}).items():
             flat("finetune_" + m.replace("+", "_plus_"), r, ("logits_max_rel",))
         if head.get("grad_sync") or world > 1:

@@ -61,7 +61,6 @@ struct GemmArgs {
   int ksteps_split;  // k-steps per split
   float* xsum;         // grouped wgrad: xsum[m] += sum_k X(m, k) (= the bias gradient: column sums of dY), or NULL
   int xsum_store;      // xsum[m] = ... instead of += (partial row sums of a k-slice, reduced later)
-  int warm_epilogue;   // pull the tile's epilogue operand (f32 residual / saved pre-activation) into the L2 at tile start (see gemm_v3_tile)
   int col_major;       // tile index -> (tm, tn): 0 row by row, 1 column by column (grouped wgrad: see wgrad_group_kernel), >= 2: row by
                        // row inside bands of that many tile columns (wide-N GEMMs: see gemm_dispatch)
 #ifdef PM_GEMM_STAMP
@@ -718,34 +717,6 @@ __device__ __forceinline__ void gemm_v3_tile(GemmArgs& a, const int tile, const 
     for (int j = 0; j < MT; ++j) xs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // Epilogue operands into the L2 while the k-loop runs (experiment 12, round 4).  The f32-residual and dGELU epilogues read a tile of
-  // a tensor nobody has touched for a while (the residual stream; the pre-activation saved by the forward pass): two to four batches
-  // of loads per wave, each exposing a trip beyond the L2 with the MFMA pipe idle.  LDS-DMA moves bytes without a VGPR destination,
-  // so one 16-B piece per 128-B line of that tile, sent to a scratch KiB per wave behind the ring, costs 2-4 wave instructions, is
-  // the OLDEST entry of the in-order vmcnt (every counted wait of the ring still means what it meant) and has long landed when
-  // the loop ends; the epilogue's loads then hit the L2.
-  if (a.warm_epilogue) {
-    const int epi0 = a.epilogue;
-    const char* src = epi0 == PM_EPI_RESIDUAL ? reinterpret_cast<const char*>(a.resid)
-                      : epi0 == PM_EPI_DGELU  ? reinterpret_cast<const char*>(a.aux)
-                      : epi0 == PM_EPI_ACCUM  ? reinterpret_cast<const char*>(a.C) : nullptr;
-    if (src) {
-      const int esz = epi0 == PM_EPI_DGELU ? 2 : 4;
-      const int lpr = BN_ * esz / 128;                       // 128-B lines per tile row
-      const int pieces = BM_ * lpr / 64;                     // wave instructions for the tile
-      char* junk = smem + STAGES * SB + wave * 1024;
-      for (int p = wave; p < pieces; p += NW) {
-        const int idx = p * 64 + lane;
-        int row = m0 + idx / lpr;
-        row = row < a.M ? row : a.M - 1;
-        long col_b = (long)n0 * esz + (idx % lpr) * 128;
-        const long row_b = (long)a.N * esz;                  // bytes of the valid part of a row
-        col_b = col_b + 16 <= row_b ? col_b : row_b - 16;
-        glds16(src + (long)row * a.ldc * esz + col_b, junk);
-      }
-    }
-  }
-
   auto issue = [&](int t) {
     char* buf = smem + (t % STAGES) * SB;
     if constexpr (XK) v3_stage_km<BM_, NW>(buf, X, a.ldx, m0, a.M, t * V3_KE, wave, lane);
@@ -1282,7 +1253,7 @@ __device__ __forceinline__ void group_item(const WgradGroupArgs& g, const int w)
     a.X = pr.dY; a.W = pr.X; a.ldx = pr.lddy; a.ldw = pr.ldx; a.bias = nullptr; a.C = pr.dW; a.ldc = pr.lddw; a.aux = nullptr;
     a.resid = nullptr; a.M = pr.M; a.N = pr.N; a.K = g.K; a.epilogue = pr.accumulate ? PM_EPI_ACCUM : PM_EPI_STORE;
     a.c_dtype = PM_F32; a.tiles_m = pr.tiles_m; a.tiles_n = pr.tiles_n; a.split_k = 1; a.ksteps_split = 0;
-    a.xsum = pr.dbias; a.xsum_store = 0; a.warm_epilogue = 0;
+    a.xsum = pr.dbias; a.xsum_store = 0;
     // Consecutive work items run on one XCD (xcd_remap) at the same pace, so what they share they fetch once into that XCD's
     // L2: a tile reads a dY panel [K x 256] and an X panel [K x 256] (6.4 MB each at K = 12 608).  Walk the SHORTER side of the
     // problem fastest, so that a run of ~13 tiles covers a compact rectangle: fc2's gradient is 3 x 12 tiles -- row by row a run
@@ -1373,7 +1344,7 @@ template <typename E>
 int launch_v3_m16(GemmArgs a, hipStream_t s) {
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.N + 255) / 256;
-  constexpr int ring = 4 * 512 * 64 + 8 * 1024, stage = 8 * V3_STAGE_WAVE;   // (+ 1 KiB of warm-up scratch per wave)
+  constexpr int ring = 4 * 512 * 64, stage = 8 * V3_STAGE_WAVE;
   const size_t lds = ring > stage ? ring : stage;
   auto kern = gemm_v3_kernel<256, 256, 2, 4, false, 4, 2, false, true, false, 8, false, true, E>;
   PM_ALLOW_LDS(kern, lds);
@@ -1385,7 +1356,7 @@ template <typename E, int BM_, int BN_, int WM, int WN, int STAGES, int MINW, bo
 int launch_v3(GemmArgs a, int wk, hipStream_t s) {
   a.tiles_m = (a.M + BM_ - 1) / BM_;
   a.tiles_n = (a.N + BN_ - 1) / BN_;
-  constexpr int ring = STAGES * (BM_ + BN_) * 64 + NW * 1024;   // (+ 1 KiB of warm-up scratch per wave, see gemm_v3_tile)
+  constexpr int ring = STAGES * (BM_ + BN_) * 64;
   constexpr int stage = DIRECT ? 0 : NW * V3_STAGE_WAVE;
   const size_t lds = ring > stage ? ring : stage;
   const dim3 grid(a.tiles_m * a.tiles_n), block(NW * 64);
@@ -1577,10 +1548,6 @@ int few_tiles_threshold() {  // tuning hook, read once: PM_FEW_TILES=0 keeps eve
   static const int v = [] { const char* e = getenv("PM_FEW_TILES"); return e && e[0] ? atoi(e) : 128; }();
   return v;
 }
-int warm_epilogue() {  // A/B switch, read once: PM_EPI_WARM=1 pulls the epilogue operand's tile into the L2 at tile start
-  static const int v = [] { const char* e = getenv("PM_EPI_WARM"); return e && e[0] ? atoi(e) : 0; }();
-  return v;
-}
 int tile_band() {  // tuning hook, read once: forward / dgrad tiles walk bands of PM_TILE_BAND tile columns (default 6; 0: row by row)
   static const int v = [] { const char* e = getenv("PM_TILE_BAND"); return e && e[0] ? atoi(e) : 6; }();
   return v;
@@ -1645,7 +1612,6 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
     const int tn256 = (N + 255) / 256;
     if (band >= 2 && tn256 > band && !a_kmajor) a.col_major = band;
   }
-  a.warm_epilogue = warm_epilogue() && !a_kmajor;   // (ring kernels only; experiment 12, see gemm_v3_tile)
 #ifdef PM_GEMM_STAMP
   a.stamps = g_stamps;
 #endif
