@@ -275,6 +275,62 @@ __device__ __forceinline__ f32x4 gelu_erf_grad4(f32x4 v) {
   return f32x4{a[0], a[1], b[0], b[1]};
 #endif
 }
+// 16-bit precision modes: Phi(x) without the quarter-rate rcp and exp2 -- an odd polynomial on the clamped argument,
+//   Phi(x) ~= 0.5 + xc Q(t),  xc = clamp(x, -4.5, 4.5),  t = 2 xc^2 / 4.5^2 - 1,  Q of degree 10 by Horner (weighted least-squares
+//   fit iterated towards minimax; evaluated in f32 with FMAs: |error| <= 2.8e-6 over all x, 1 - Phi(4.5) = 3.4e-6 being the floor of
+//   the clamp).  The outputs of these epilogues are rounded to bf16 (relative 2e-3) or fp16 (5e-4) next, so the approximation sits two
+//   to three orders below the rounding it feeds; fp32 mode keeps the 1.5e-7 form above.  8 issue slots per element as packed f32
+//   math instead of 17 (experiment 14: the GELU epilogue is half of an fc1 launch, ~10 us of VALU per tile with no MFMA to hide behind).
+//   The derivative keeps exp(-x^2/2) for the pdf term: one exp2, no rcp (14 slots instead of 19).
+//   MEASURED (experiment 15, profiles/r4_exp15_*): fc1 + GELU 64.2 -> 59.7 us stand-alone at M = 6 304 (103.0 -> 99.3 at 12 608), dGELU
+//   dgrad -1.7 %, the step +0.3 % -- and every bf16 rounding decision downstream is re-rolled, which moved the noisiest gated quantity
+//   (worst weight-gradient rel-L2 of the bf16 classifier at B = 64: 3.0e-2 measured with the erf form, 3.9e-2 in the CPU emulation of
+//   the rounding points) to 4.15e-2, past a gate that is "measured + 25 %".  Not worth a re-gate for +0.3 %: OFF by default,
+//   -DPM_GELU_POLY (scratch/build_alt.sh) builds it.
+#ifdef PM_GELU_POLY
+__device__ __forceinline__ f32x2 phi_poly2(f32x2 x) {
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(x[0], -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x[1], -4.5f, 4.5f)};
+  const f32x2 t = __builtin_elementwise_fma(xc * xc, f32x2{0.09876543283462524f, 0.09876543283462524f}, f32x2{-1.0f, -1.0f});
+  f32x2 q = {8.193445974e-04f, 8.193445974e-04f};
+  q = __builtin_elementwise_fma(q, t, f32x2{-2.259161090e-03f, -2.259161090e-03f});
+  q = __builtin_elementwise_fma(q, t, f32x2{3.079207381e-03f, 3.079207381e-03f});
+  q = __builtin_elementwise_fma(q, t, f32x2{-5.413250532e-03f, -5.413250532e-03f});
+  q = __builtin_elementwise_fma(q, t, f32x2{1.115704700e-02f, 1.115704700e-02f});
+  q = __builtin_elementwise_fma(q, t, f32x2{-1.891482994e-02f, -1.891482994e-02f});
+  q = __builtin_elementwise_fma(q, t, f32x2{2.837207168e-02f, 2.837207168e-02f});
+  q = __builtin_elementwise_fma(q, t, f32x2{-4.013447464e-02f, -4.013447464e-02f});
+  q = __builtin_elementwise_fma(q, t, f32x2{5.469175428e-02f, 5.469175428e-02f});
+  q = __builtin_elementwise_fma(q, t, f32x2{-7.719228417e-02f, -7.719228417e-02f});
+  q = __builtin_elementwise_fma(q, t, f32x2{1.569050848e-01f, 1.569050848e-01f});
+  return __builtin_elementwise_fma(xc, q, f32x2{0.5f, 0.5f});
+}
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) { return x * phi_poly2(x); }
+__device__ __forceinline__ f32x2 gelu_poly_grad2(f32x2 x) {
+  const f32x2 a = (x * -0.72134752044448170368f) * x;
+  const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};  // exp(-x^2/2)
+  return __builtin_elementwise_fma(x * 0.39894228040143267794f, e, phi_poly2(x));
+}
+#endif
+// GELU / its derivative as the epilogues of activation type T apply them: the polynomial Phi for the 16-bit types, the erf form for f32
+// when built with -DPM_GELU_POLY; the erf form everywhere otherwise (the default)
+template <typename T> __device__ __forceinline__ f32x4 gelu_act4(f32x4 v) {
+#ifdef PM_GELU_POLY
+  if constexpr (sizeof(T) == 2) {
+    const f32x2 a = gelu_poly2(f32x2{v[0], v[1]}), b = gelu_poly2(f32x2{v[2], v[3]});
+    return f32x4{a[0], a[1], b[0], b[1]};
+  }
+#endif
+  return gelu_erf4(v);
+}
+template <typename T> __device__ __forceinline__ f32x4 gelu_act_grad4(f32x4 v) {
+#ifdef PM_GELU_POLY
+  if constexpr (sizeof(T) == 2) {
+    const f32x2 a = gelu_poly_grad2(f32x2{v[0], v[1]}), b = gelu_poly_grad2(f32x2{v[2], v[3]});
+    return f32x4{a[0], a[1], b[0], b[1]};
+  }
+#endif
+  return gelu_erf_grad4(v);
+}
 // the value the backward pass will see: the pre-activation after its round trip through the activation dtype
 template <typename T> __device__ __forceinline__ f32x4 round_through(f32x4 v) {
   return f32x4{to_f32<T>(from_f32<T>(v[0])), to_f32<T>(from_f32<T>(v[1])), to_f32<T>(from_f32<T>(v[2])), to_f32<T>(from_f32<T>(v[3]))};

@@ -61,6 +61,7 @@ struct GemmArgs {
   int ksteps_split;  // k-steps per split
   float* xsum;         // grouped wgrad: xsum[m] += sum_k X(m, k) (= the bias gradient: column sums of dY), or NULL
   int xsum_store;      // xsum[m] = ... instead of += (partial row sums of a k-slice, reduced later)
+  int epi_hoist;       // gemm_glds_kernel: the sixteen epilogue loads of a wave tile in one batch (0: one load -> store chain per vector)
   int col_major;       // tile index -> (tm, tn): 0 row by row, 1 column by column (grouped wgrad: see wgrad_group_kernel), >= 2: row by
                        // row inside bands of that many tile columns (wide-N GEMMs: see gemm_dispatch)
 #ifdef PM_GEMM_STAMP
@@ -247,10 +248,10 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int epi, long off, 
   } else {
     if (epi == PM_EPI_GELU) {
       store4<T>(reinterpret_cast<T*>(a.aux) + off, v);
-      v = gelu_erf4(round_through<T>(v));  // gelu of the value backward will see
+      v = gelu_act4<T>(round_through<T>(v));  // gelu of the value backward will see
     } else if (epi == PM_EPI_DGELU) {
       const f32x4 pre = load4<T>(reinterpret_cast<const T*>(a.aux) + off);
-      v *= gelu_erf_grad4(pre);
+      v *= gelu_act_grad4<T>(pre);
     }
     if (a.c_dtype == PM_F32) {
       store4<float>(reinterpret_cast<float*>(a.C) + off, v);
@@ -285,12 +286,12 @@ __device__ __forceinline__ void epilogue_batch(const GemmArgs& a, int epi, const
 #pragma unroll
     for (int e = 0; e < NV; ++e) pre[e] = load4<E>(reinterpret_cast<const E*>(a.aux) + off[e]);
 #pragma unroll
-    for (int e = 0; e < NV; ++e) v[e] *= gelu_erf_grad4(pre[e]);
+    for (int e = 0; e < NV; ++e) v[e] *= gelu_act_grad4<E>(pre[e]);
   } else if (epi == PM_EPI_GELU) {
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
       if (ok[e]) store4<E>(reinterpret_cast<E*>(a.aux) + off[e], v[e]);
-      v[e] = gelu_erf4(round_through<E>(v[e]));  // what backward will see
+      v[e] = gelu_act4<E>(round_through<E>(v[e]));  // what backward will see
     }
   }
   if (a.c_dtype == PM_F32) {
@@ -314,15 +315,15 @@ __device__ __forceinline__ void epilogue_batch8(const GemmArgs& a, int epi, cons
     for (int u = 0; u < NV; ++u) load8_16<E>(reinterpret_cast<const E*>(a.aux) + off[u], plo[u], phi[u]);
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      lo[u] *= gelu_erf_grad4(plo[u]);
-      hi[u] *= gelu_erf_grad4(phi[u]);
+      lo[u] *= gelu_act_grad4<E>(plo[u]);
+      hi[u] *= gelu_act_grad4<E>(phi[u]);
     }
   } else if (epi == PM_EPI_GELU) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       if (ok[u]) store8_16<E>(reinterpret_cast<E*>(a.aux) + off[u], lo[u], hi[u]);
-      lo[u] = gelu_erf4(round_through<E>(lo[u]));  // gelu of the value backward will see (the rounded pre-activation)
-      hi[u] = gelu_erf4(round_through<E>(hi[u]));
+      lo[u] = gelu_act4<E>(round_through<E>(lo[u]));  // gelu of the value backward will see (the rounded pre-activation)
+      hi[u] = gelu_act4<E>(round_through<E>(hi[u]));
     }
   }
 #pragma unroll
@@ -405,6 +406,28 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(GemmArgs a) {
   const int epi = split ? PM_EPI_STORE : a.epilogue;
   float* slab = split ? reinterpret_cast<float*>(a.C) + (long)blockIdx.y * a.M * a.ldc : nullptr;
   const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+  if (!split && a.epi_hoist && (sizeof(T) == 2 || a.c_dtype == PM_F32)) {  // (f32 operands with a 16-bit C: the per-vector path below)
+    // every load the epilogue needs for the wave's 64 x 64 tile (f32 residual / C, or the saved pre-activation) is issued before the
+    // first store: one exposed trip to memory per tile instead of sixteen load -> store chains (the compiler cannot hoist a load over
+    // a store that may alias it).  Clamped addresses for rows / columns beyond M / N, the stores are gated.
+    const int c4 = (lane & 15) * 4, n = nw + c4;
+    const bool nok = n < a.N;
+    const long ncl = nok ? n : a.N - 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + ncl);
+    long off[16];
+    bool ok[16];
+    f32x4 v[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int ml = it * 4 + (lane >> 4), m = mw + ml;
+      ok[it] = m < a.M && nok;
+      off[it] = (long)(m < a.M ? m : a.M - 1) * a.ldc + ncl;
+      v[it] = *reinterpret_cast<const f32x4*>(st + ml * STAGE_ROW + c4 * 4) + bv;
+    }
+    epilogue_batch<T, 16>(a, epi, off, ok, v);
+    return;
+  }
 #pragma unroll 4
   for (int it = 0; it < 16; ++it) {
     const int ml = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
@@ -1253,7 +1276,7 @@ __device__ __forceinline__ void group_item(const WgradGroupArgs& g, const int w)
     a.X = pr.dY; a.W = pr.X; a.ldx = pr.lddy; a.ldw = pr.ldx; a.bias = nullptr; a.C = pr.dW; a.ldc = pr.lddw; a.aux = nullptr;
     a.resid = nullptr; a.M = pr.M; a.N = pr.N; a.K = g.K; a.epilogue = pr.accumulate ? PM_EPI_ACCUM : PM_EPI_STORE;
     a.c_dtype = PM_F32; a.tiles_m = pr.tiles_m; a.tiles_n = pr.tiles_n; a.split_k = 1; a.ksteps_split = 0;
-    a.xsum = pr.dbias; a.xsum_store = 0;
+    a.xsum = pr.dbias; a.xsum_store = 0; a.epi_hoist = 0;
     // Consecutive work items run on one XCD (xcd_remap) at the same pace, so what they share they fetch once into that XCD's
     // L2: a tile reads a dY panel [K x 256] and an X panel [K x 256] (6.4 MB each at K = 12 608).  Walk the SHORTER side of the
     // problem fastest, so that a run of ~13 tiles covers a compact rectangle: fc2's gradient is 3 x 12 tiles -- row by row a run
@@ -1548,6 +1571,11 @@ int few_tiles_threshold() {  // tuning hook, read once: PM_FEW_TILES=0 keeps eve
   static const int v = [] { const char* e = getenv("PM_FEW_TILES"); return e && e[0] ? atoi(e) : 128; }();
   return v;
 }
+// A/B switch, read once on the host and carried in GemmArgs: PM_EPI_HOIST=0 restores the 128 x 128 kernel's per-vector epilogue
+int epi_hoist_host() {
+  static const int v = [] { const char* e = getenv("PM_EPI_HOIST"); return e && e[0] ? atoi(e) : 1; }();
+  return v;
+}
 int tile_band() {  // tuning hook, read once: forward / dgrad tiles walk bands of PM_TILE_BAND tile columns (default 6; 0: row by row)
   static const int v = [] { const char* e = getenv("PM_TILE_BAND"); return e && e[0] ? atoi(e) : 6; }();
   return v;
@@ -1606,6 +1634,7 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
   // columns a run is ~12 row blocks x 6 panels: the band's W (2.4 MB) stays in the L2 while the row blocks stream through once.
   // Measured (profiles/r4_exp11_tile_bands.txt): dGELU dgrad 205.7 -> 172.7 MB fetched, fc1 + GELU 67.5 -> 57.7 MB; stand-alone fc1 + GELU
   // 99.5 -> 95.9 us; in the step +0.6 ... +1.2 % (cls), +0.7 % (MAE bs = 256), two same-box rounds each.
+  a.epi_hoist = epi_hoist_host();
   a.col_major = 0;
   {
     const int band = tile_band();

@@ -240,7 +240,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void dgelu_kernel(const T* __restrict__ dy, const T* __restrict__ pre, T* __restrict__ out, long n) {
   const long nvec = n >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256)
-    store4<T>(out + 4 * i, load4<T>(dy + 4 * i) * gelu_erf_grad4(load4<T>(pre + 4 * i)));
+    store4<T>(out + 4 * i, load4<T>(dy + 4 * i) * gelu_act_grad4<T>(load4<T>(pre + 4 * i)));
 }
 
 // ---------------------------------------------------------------------------------------------
