@@ -343,14 +343,9 @@ __device__ __forceinline__ void swap_halves(float& x, float& y) {
 // ------------------------------------------------------------------------------------------------
 // fast path
 // ------------------------------------------------------------------------------------------------
-// NBUF = 2: double buffer, two workgroups per CU -- one workgroup's wait for its next k-stage runs under the other's MFMAs.
-// NBUF = 3 (round 4, experiment 18): three buffers, the DMA of stage t+2 issued while stage t computes, counted
-// s_waitcnt vmcnt(8) (a stage is 8 LDS-DMA instructions per wave: 4 of X, 4 of W) -- for launches of at most one workgroup per CU
-// (the MAE encoder at bs = 64 / GPU: 78-234 tiles), where nobody else covers the wait: a k-step's 16 MFMAs per wave take ~0.25 us,
-// a stage needs ~0.5 us from the L2, and with one stage of prefetch the difference is exposed twelve times per K = 768 tile.
-template <typename T, bool XK, bool WK, int NBUF = 2>
-__global__ __launch_bounds__(kThreads, NBUF == 2 ? 2 : 1) void gemm_glds_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NBUF buffers][X tile | W tile]; reused for staging
+template <typename T, bool XK, bool WK>
+__global__ __launch_bounds__(kThreads, 2) void gemm_glds_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][X tile | W tile]; reused for staging
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -372,29 +367,7 @@ __global__ __launch_bounds__(kThreads, NBUF == 2 ? 2 : 1) void gemm_glds_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if constexpr (NBUF == 3) {
-    if (kbeg < kend) {
-      auto issue = [&](int t, int buf) {
-        char* b = smem + buf * 2 * TILE_BYTES;
-        stage_glds<T, XK>(b, X, a.ldx, m0, a.M, t * KE, wave, lane);
-        stage_glds<T, WK>(b + TILE_BYTES, W, a.ldw, n0, a.N, t * KE, wave, lane);
-      };
-      issue(kbeg, 0);
-      if (kbeg + 1 < kend) issue(kbeg + 1, 1);
-      int cur = 0;  // buffer of stage t; stage t+2 goes into the buffer stage t-1 left
-      for (int t = kbeg; t < kend; ++t) {
-        if (t + 1 < kend) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's pieces of stage t landed, stage t+1 may fly
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // everyone's pieces of stage t landed; everyone finished reading stage t-1
-        const int prev = cur == 0 ? 2 : cur - 1;
-        if (t + 2 < kend) issue(t + 2, prev);
-        const char* bx = smem + cur * 2 * TILE_BYTES;
-        mma_kstep<T, XK, WK>(bx, bx + TILE_BYTES, wm, wn, lane, acc);
-        cur = cur == 2 ? 0 : cur + 1;
-      }
-      __syncthreads();  // the epilogue staging reuses the buffers: every wave is done reading them
-    }
-  } else if (kbeg < kend) {
+  if (kbeg < kend) {
     stage_glds<T, XK>(smem, X, a.ldx, m0, a.M, kbeg * KE, wave, lane);
     stage_glds<T, WK>(smem + TILE_BYTES, W, a.ldw, n0, a.N, kbeg * KE, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1450,42 +1423,28 @@ int launch_generic(const GemmArgs& a, int xk, int wk, hipStream_t s) {
   return pm_check_launch();
 }
 
-// launches of at most this many workgroups (one per CU or fewer) take the three-buffer loop; PM_GLDS_RING=0 turns it off
-int glds_ring_max_blocks() {
-  static const int v = [] { const char* e = getenv("PM_GLDS_RING"); return e && e[0] ? atoi(e) : 256; }();
-  return v;
-}
-
-template <typename T, int NBUF>
-int launch_glds_n(const GemmArgs& a, int xk, int wk, hipStream_t s) {
+template <typename T>
+int launch_glds(const GemmArgs& a, int xk, int wk, hipStream_t s) {
   const dim3 grid(a.tiles_m * a.tiles_n, a.split_k), block(kThreads);
-  constexpr size_t ring = (size_t)NBUF * 2 * TILE_BYTES;
-  const size_t lds = ring > (size_t)GLDS_LDS_BYTES ? ring : (size_t)GLDS_LDS_BYTES;
+  const size_t lds = GLDS_LDS_BYTES;
   if (!xk && !wk) {
-    auto kern = gemm_glds_kernel<T, false, false, NBUF>;
+    auto kern = gemm_glds_kernel<T, false, false>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else if (!xk && wk) {
-    auto kern = gemm_glds_kernel<T, false, true, NBUF>;
+    auto kern = gemm_glds_kernel<T, false, true>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else if (xk && wk) {
-    auto kern = gemm_glds_kernel<T, true, true, NBUF>;
+    auto kern = gemm_glds_kernel<T, true, true>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   } else {
-    auto kern = gemm_glds_kernel<T, true, false, NBUF>;
+    auto kern = gemm_glds_kernel<T, true, false>;
     PM_ALLOW_LDS(kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, s, a);
   }
   return pm_check_launch();
-}
-
-template <typename T>
-int launch_glds(const GemmArgs& a, int xk, int wk, hipStream_t s) {
-  const long blocks = (long)a.tiles_m * a.tiles_n * a.split_k;
-  if (blocks <= glds_ring_max_blocks()) return launch_glds_n<T, 3>(a, xk, wk, s);
-  return launch_glds_n<T, 2>(a, xk, wk, s);
 }
 
 // the ring-kernel variants the dispatcher chooses from (cfg: see gemm_dispatch), per 16-bit operand type
