@@ -290,6 +290,23 @@ typedef struct pm_aug_geom {
 int pm_aug_geometry_u8(const unsigned char* src, const pm_aug_geom* geom, void* dst, int to_f32, int B, int H, int W, float mean_r,
                        float mean_g, float mean_b, float std_r, float std_g, float std_b, void* stream);
 
+/* Eval-time perturbations of PerRowPerturbations (classification/data/transforms.py:143-203; Exp-5A/5B feed them to the evaluation
+ * forward path) on the resized uint8 frames, u8 [B][H][W][3]:
+ *   "blur*": ImageFilter.GaussianBlur(radius=sigma) = Pillow's BoxBlur.c, `passes` extended-box passes per axis in UINT32 fixed
+ *            point.  Per sample: radius = (int) r, ww = (UINT32)((float) 2^24 / (r * 2 + 1)), fw = (2^24 - (2 radius + 1) ww) / 2
+ *            with r = _gaussian_blur_radius(sigma, passes) in float32 (built by the caller: data.py pil_box_blur_params);
+ *            radius < 0: the sample passes through unchanged.  tmp: u8 [B][H][W][3] scratch; src may equal dst, tmp must not.
+ *   "occ*":  ImageDraw.rectangle([x0, y0, x1, y1], fill=0), corners inclusive, clipped to the frame; x1 < x0: nothing.  In place.
+ *   "bc*":   pm_aug_color_jitter_u8 with order {0, 1, -1, -1}.      "jpeg*": a codec round trip; host side, like decoding.
+ * Bit for bit against oracle/augment_ref.py, which is pinned by running the reference's own PerRowPerturbations (Pillow 12.2). */
+typedef struct pm_aug_boxblur {
+  int radius;
+  unsigned int ww, fw;
+} pm_aug_boxblur;
+int pm_aug_pil_gaussian_blur_u8(const unsigned char* src, unsigned char* tmp, unsigned char* dst, const pm_aug_boxblur* prm,
+                                int passes, int B, int H, int W, void* stream);
+int pm_aug_occlude_u8(unsigned char* img, const int* rects, int B, int H, int W, void* stream);
+
 /* One transformer block forward for one range of samples in ONE call (timm Block: models_mae.py:39-41,53-55,166-167,
  * 186-187; models.py:122-123,204-205):  x_mid = x + proj(attn(LN1 x));  x_out = x_mid + fc2(gelu(fc1(LN2 x_mid))).
  * Host-side composition of pm_layernorm_fwd / pm_gemm_ex / pm_attention_fwd on `stream`, launch for launch what a caller

@@ -307,3 +307,77 @@ def train_augment(frames: np.ndarray, params: dict) -> np.ndarray:
         x = rotate_nearest(np.ascontiguousarray(x), float(params["angle"][b]))
         out[b] = x[0]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Eval-time perturbations (classification/data/transforms.py:78-120, applied by PerRowPerturbations :143-203 between Resize and
+# ToTensor): the pixel arithmetic of the three that are not a codec.  PINNED by running the reference's own PerRowPerturbations
+# in the build container (tests/golden/make_perturb_fixtures.py -> tests/golden/perturb.npz; Pillow 12.2 underneath).
+#   blur  img.filter(ImageFilter.GaussianBlur(radius=sigma))      Pillow src/libImaging/BoxBlur.c: ImagingGaussianBlur = three
+#         "extended box" passes per axis (Gwosdek et al.): integer radius + a fractional weight on the two pixels beyond it
+#   bc    ImageEnhance.Brightness(img).enhance(b), then ImageEnhance.Contrast(img).enhance(c)   (adjust_brightness / _contrast above)
+#   occ   ImageDraw.Draw(img).rectangle([x0, y0, x1, y1], fill=(0, 0, 0)): both corners inclusive
+# ---------------------------------------------------------------------------------------------------------------------
+def pil_gaussian_box_radius(sigma: float, passes: int = 3) -> np.float32:
+    """BoxBlur.c _gaussian_blur_radius: float variables, double intermediates where the C constants are double."""
+    f32 = np.float32
+    s = f32(sigma)
+    sigma2 = f32(s * s / f32(passes))
+    big_l = f32(math.sqrt(12.0 * float(sigma2) + 1.0))
+    l = f32(math.floor((float(big_l) - 1.0) / 2.0))
+    a = f32((f32(2) * l + f32(1)) * (l * (l + f32(1)) - f32(3) * sigma2))
+    a = f32(a / f32(f32(6) * (sigma2 - (l + f32(1)) * (l + f32(1)))))
+    return f32(l + a)
+
+
+def _box_blur_lines(x: np.ndarray, fr: np.float32) -> np.ndarray:
+    """One ImagingHorizontalBoxBlur pass along axis -2 of uint8 [..., n, C].  The C code carries a running sum along the line; each
+    output equals  (ww * sum_{|d| <= radius} in[clamp(x + d)] + fw * (in[clamp(x - radius - 1)] + in[clamp(x + radius + 1)]) + 2^23) >> 24
+    in UINT32 arithmetic, with  ww = (UINT32)((float) 2^24 / (fr * 2 + 1)),  fw = (2^24 - (2 radius + 1) * ww) / 2."""
+    f32 = np.float32
+    radius = int(fr)
+    ww = np.uint64(np.uint32(f32(16777216.0) / f32(fr * f32(2) + f32(1))))
+    fw = np.uint64(((1 << 24) - (radius * 2 + 1) * int(ww)) // 2 & 0xFFFFFFFF)
+    n = x.shape[-2]
+    idx = np.arange(n)
+    xi = x.astype(np.uint64)
+    acc = np.zeros_like(xi)
+    for d in range(-radius, radius + 1):
+        acc += np.take(xi, np.clip(idx + d, 0, n - 1), axis=-2)
+    far = np.take(xi, np.clip(idx - radius - 1, 0, n - 1), axis=-2) + np.take(xi, np.clip(idx + radius + 1, 0, n - 1), axis=-2)
+    mask = np.uint64(0xFFFFFFFF)
+    bulk = (acc * ww + far * fw) & mask
+    return (((bulk + np.uint64(1 << 23)) & mask) >> np.uint64(24)).astype(np.uint8)
+
+
+def pil_gaussian_blur(img: np.ndarray, sigma: float, passes: int = 3) -> np.ndarray:
+    """ImageFilter.GaussianBlur(radius=sigma) on uint8 [H, W, 3]: `passes` box passes along x, then along y (ImagingBoxBlur)."""
+    r = pil_gaussian_box_radius(sigma, passes)
+    out = img
+    if r > 0:
+        for _ in range(passes):
+            out = _box_blur_lines(out, r)
+        out = np.swapaxes(out, 0, 1)
+        for _ in range(passes):
+            out = _box_blur_lines(out, r)
+        out = np.swapaxes(out, 0, 1)
+    return np.ascontiguousarray(out)
+
+
+def occlude(img: np.ndarray, rect) -> np.ndarray:
+    """ImageDraw.rectangle([x0, y0, x1, y1], fill=0): corners inclusive, clipped to the image."""
+    out = img.copy()
+    if rect is not None:
+        x0, y0, x1, y1 = rect
+        out[max(0, y0):min(img.shape[0] - 1, y1) + 1, max(0, x0):min(img.shape[1] - 1, x1) + 1] = 0
+    return out
+
+
+def brightness_contrast(img: np.ndarray, brightness, contrast) -> np.ndarray:
+    """transforms.py:88-96: each enhancement only when its factor is given and positive, brightness first."""
+    out = img
+    if brightness is not None and brightness > 0:
+        out = adjust_brightness(out[None], brightness)[0]
+    if contrast is not None and contrast > 0:
+        out = adjust_contrast(out[None], contrast)[0]
+    return out

@@ -365,10 +365,85 @@ __global__ __launch_bounds__(256) void geom_kernel(const unsigned char* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The eval-time perturbations of PerRowPerturbations (classification/data/transforms.py:143-203) that are pixel arithmetic:
+//   "blur*"  img.filter(ImageFilter.GaussianBlur(radius=sigma))  = Pillow BoxBlur.c ImagingGaussianBlur: three passes of an
+//            "extended box" per axis -- integer radius r plus a fractional weight on the two pixels beyond it -- in UINT32 fixed
+//            point: out = (ww * sum_{|d| <= r} in[x + d] + fw * (in[x - r - 1] + in[x + r + 1]) + 2^23) >> 24, indices clamped
+//            to the line (the C code keeps a running sum along the line; every output is this window);
+//   "occ*"   ImageDraw.rectangle([x0, y0, x1, y1], fill=0): both corners inclusive.
+// ("bc*" is two ImageEnhance blends: pm_aug_color_jitter_u8 with order {0, 1, -1, -1}; "jpeg*" is a codec round trip and stays
+// on the host like the decoding itself.)  r, ww, fw come from the host per sample (float32 arithmetic of ImagingHorizontalBoxBlur).
+// ---------------------------------------------------------------------------------------------
+struct BoxBlur {
+  int radius;            // < 0: this sample is not blurred (the pass copies it)
+  unsigned int ww, fw;
+};
+
+// one pass along x (axis = 0) or y (axis = 1) of every sample: u8 [B][H][W][3] -> the same
+__global__ __launch_bounds__(256) void box_blur_pass_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                            const BoxBlur* __restrict__ prm, int axis, int B, int H, int W) {
+  const long total = (long)B * H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int b = i / ((long)H * W);
+    const int rem = i % ((long)H * W);
+    const int y = rem / W, x = rem % W;
+    const unsigned char* img = src + (long)b * H * W * 3;
+    const BoxBlur p = prm[b];
+    unsigned char* o = dst + i * 3;
+    if (p.radius < 0) {
+      o[0] = img[(long)rem * 3];
+      o[1] = img[(long)rem * 3 + 1];
+      o[2] = img[(long)rem * 3 + 2];
+      continue;
+    }
+    const int n = axis == 0 ? W : H, pos = axis == 0 ? x : y;
+    const long step = axis == 0 ? 3 : (long)W * 3;
+    const unsigned char* line = img + (axis == 0 ? (long)y * W * 3 : (long)x * 3);
+    unsigned int acc[3] = {0u, 0u, 0u};
+    for (int d = -p.radius; d <= p.radius; ++d) {
+      int q = pos + d;
+      q = q < 0 ? 0 : (q > n - 1 ? n - 1 : q);
+      const unsigned char* px = line + q * step;
+      acc[0] += px[0];
+      acc[1] += px[1];
+      acc[2] += px[2];
+    }
+    int ql = pos - p.radius - 1, qr = pos + p.radius + 1;
+    ql = ql < 0 ? 0 : ql;
+    qr = qr > n - 1 ? n - 1 : qr;
+    const unsigned char* pl = line + ql * step;
+    const unsigned char* pr = line + qr * step;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const unsigned int bulk = acc[c] * p.ww + ((unsigned int)pl[c] + (unsigned int)pr[c]) * p.fw;  // UINT32 wrap-around as in C
+      o[c] = (unsigned char)((bulk + (1u << 23)) >> 24);
+    }
+  }
+}
+
+// rects: int [B][4] = x0, y0, x1, y1 (inclusive; x1 < x0: nothing drawn), in place
+__global__ __launch_bounds__(256) void occlude_kernel(unsigned char* __restrict__ img, const int* __restrict__ rects, int B, int H, int W) {
+  const int b = blockIdx.y;
+  int x0 = rects[4 * b], y0 = rects[4 * b + 1], x1 = rects[4 * b + 2], y1 = rects[4 * b + 3];
+  x0 = x0 < 0 ? 0 : x0;
+  y0 = y0 < 0 ? 0 : y0;
+  x1 = x1 > W - 1 ? W - 1 : x1;
+  y1 = y1 > H - 1 ? H - 1 : y1;
+  if (x1 < x0 || y1 < y0) return;
+  const int rw = x1 - x0 + 1, rh = y1 - y0 + 1;
+  const long total = (long)rw * rh * 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int yy = i / (rw * 3), r = i % (rw * 3);
+    img[((long)b * H + y0 + yy) * W * 3 + (long)x0 * 3 + r] = 0;
+  }
+}
+
 }  // namespace
 
 static_assert(sizeof(Jitter) == sizeof(pm_aug_jitter), "pm_aug_jitter layout");
 static_assert(sizeof(Geom) == sizeof(pm_aug_geom), "pm_aug_geom layout");
+static_assert(sizeof(BoxBlur) == sizeof(pm_aug_boxblur), "pm_aug_boxblur layout");
 
 extern "C" int pm_aug_resize_u8(const unsigned char* src, unsigned char* tmp, unsigned char* dst, const int* bounds_x,
                                 const int* taps_x, int ksize_x, const int* bounds_y, const int* taps_y, int ksize_y, int B, int Hs,
@@ -467,5 +542,31 @@ extern "C" int pm_aug_geometry_u8(const unsigned char* src, const pm_aug_geom* g
   else
     hipLaunchKernelGGL(geom_kernel<false>, dim3(g), dim3(256), 0, pm_stream(stream), src, reinterpret_cast<const Geom*>(geom), dst, B,
                        H, W, mean, stdv);
+  return pm_check_launch();
+}
+
+extern "C" int pm_aug_pil_gaussian_blur_u8(const unsigned char* src, unsigned char* tmp, unsigned char* dst, const pm_aug_boxblur* prm,
+                                           int passes, int B, int H, int W, void* stream) {
+  if (!src || !tmp || !dst || !prm) return PM_EINVAL;
+  if (B <= 0 || H <= 0 || W <= 0 || passes < 1 || passes > 8) return PM_ESHAPE;
+  if (src == tmp || tmp == dst) return PM_EINVAL;
+  const BoxBlur* p = reinterpret_cast<const BoxBlur*>(prm);
+  const int grid = aug_grid((long)B * H * W);
+  hipStream_t s = pm_stream(stream);
+  // 2 * passes launches (x passes, then y passes) ping-pong between tmp and dst so that the last one lands in dst; src is only
+  // read by the first, so src == dst is fine
+  const unsigned char* in = src;
+  for (int k = 0; k < 2 * passes; ++k) {
+    unsigned char* out = ((2 * passes - 1 - k) & 1) ? tmp : dst;
+    hipLaunchKernelGGL(box_blur_pass_kernel, dim3(grid), dim3(256), 0, s, in, out, p, k < passes ? 0 : 1, B, H, W);
+    in = out;
+  }
+  return pm_check_launch();
+}
+
+extern "C" int pm_aug_occlude_u8(unsigned char* img, const int* rects, int B, int H, int W, void* stream) {
+  if (!img || !rects) return PM_EINVAL;
+  if (B <= 0 || H <= 0 || W <= 0) return PM_ESHAPE;
+  hipLaunchKernelGGL(occlude_kernel, dim3(64, B), dim3(256), 0, pm_stream(stream), img, rects, B, H, W);
   return pm_check_launch();
 }

@@ -303,6 +303,207 @@ class DeviceAugmenter:
         return out
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Eval-time perturbations (classification/data/transforms.py:21-203): what PerRowPerturbations does to the resized PIL image of a
+# row of an Exp-5A / 5B pack, planned on the host from the row's metadata and applied to the uint8 batch on the device
+# ------------------------------------------------------------------------------------------------------------------------------------
+DEFAULT_HMAC_KEY = b"ssl4polyp"   # transforms.py:18
+_UNSET = (None, "", -1, "-1")
+_UNSET_F = (None, "", -1, "-1", "-1.0")
+
+
+def _variant_number(token: str):
+    """A number as the variant names spell it (transforms.py:30-40): 'p' is the decimal point, 'minus' / 'neg' the sign."""
+    t = token.strip().lower()
+    if not t:
+        return None
+    t = t.replace("minus", "-").replace("neg", "-").replace("p", ".")
+    try:
+        return float(t)
+    except ValueError:
+        return None
+
+
+def _last_number(variant: str):
+    """The last '_'-separated token that reads as a number (transforms.py:43-49)."""
+    for part in reversed(variant.split("_")):
+        v = _variant_number(part)
+        if v is not None:
+            return v
+    return None
+
+
+def _row_seed(row, key: bytes) -> int:
+    """transforms.py:123-140: HMAC-SHA256 over five metadata fields, first 8 bytes big-endian."""
+    import hashlib
+    import hmac
+    msg = "|".join(str(row.get(f, "")) for f in ("frame_path", "frame_id", "case_id", "variant", "perturbation_id"))
+    return int.from_bytes(hmac.new(key, msg.encode("utf-8"), hashlib.sha256).digest()[:8], "big", signed=False)
+
+
+def occlusion_rect(area_fraction: float, seed: int, width: int, height: int):
+    """transforms.py:99-120: the black rectangle of an "occ" row as (x0, y0, x1, y1), corners inclusive as ImageDraw.rectangle draws
+    them, or None.  The draws come from Python's own random.Random(seed), in the reference's order."""
+    import math
+    import random
+    a = max(0.0, min(float(area_fraction), 1.0))
+    if a <= 0:
+        return None
+    rng = random.Random(seed)
+    occ_area = max(1.0, a * (width * height))
+    aspect = rng.uniform(0.5, 2.0)
+    ow = max(1, min(width, int(round(math.sqrt(occ_area * aspect)))))
+    oh = max(1, min(height, int(round(math.sqrt(occ_area / aspect)))))
+    max_x, max_y = max(0, width - ow), max(0, height - oh)
+    x0 = rng.randint(0, max_x) if max_x > 0 else 0
+    y0 = rng.randint(0, max_y) if max_y > 0 else 0
+    return x0, y0, min(width, x0 + ow), min(height, y0 + oh)
+
+
+def perturbation_plan(row, key: bytes = DEFAULT_HMAC_KEY):
+    """What PerRowPerturbations.__call__ (transforms.py:149-203) would do for this row, as a tuple:
+    ("none",) | ("blur", sigma) | ("jpeg", quality) | ("bc", brightness or None, contrast or None) | ("occ", area_fraction, seed).
+    Field values win over what the variant name spells; a variant whose number does not parse leaves the frame alone, as there."""
+    if not row:
+        return ("none",)
+    flag = row.get("render_in_pipeline", True)
+    if flag is None or not (flag if isinstance(flag, bool) else str(flag).strip().lower() in {"1", "true", "yes", "y"}):
+        return ("none",)
+    variant = str(row.get("variant") or row.get("perturbation_id") or "").strip()
+    if not variant or variant.lower() == "clean":
+        return ("none",)
+    v = variant.lower()
+    if v.startswith("blur"):
+        f = row.get("blur_sigma")
+        sigma = float(f) if f not in _UNSET_F else _last_number(v)
+        return ("blur", sigma) if sigma is not None and sigma > 0 else ("none",)
+    if v.startswith("jpeg"):
+        f = row.get("jpeg_q")
+        q = float(f) if f not in _UNSET else _last_number(v)
+        if q is not None and f in _UNSET:
+            q = float(int(round(q)))          # (_parse_quality rounds once, the caller once more)
+        return ("jpeg", max(1, min(int(round(q)), 100))) if q is not None else ("none",)
+    if v.startswith("bc"):
+        fb, fc = row.get("brightness"), row.get("contrast")
+        b = float(fb) if fb not in _UNSET_F else None
+        c = float(fc) if fc not in _UNSET_F else None
+        pb = pc = None
+        for part in v.split("_"):
+            if part.startswith("b"):
+                pb = _variant_number(part[1:])
+            elif part.startswith("c"):
+                pc = _variant_number(part[1:])
+        return ("bc", b if b is not None else pb, c if c is not None else pc)
+    if v.startswith("occ"):
+        f = row.get("bbox_area_frac")
+        if f not in _UNSET_F:
+            area = float(f)
+        else:
+            area = _variant_number(v.split("a", 1)[1] if "a" in v else v.split("_")[-1])
+        if area is None or area <= 0:
+            return ("none",)
+        rs = row.get("rng_seed")
+        return ("occ", area, int(rs) if rs not in _UNSET else _row_seed(row, key))
+    return ("none",)
+
+
+def pil_box_blur_params(sigma: float, passes: int = 3):
+    """(radius, ww, fw) of Pillow's ImagingGaussianBlur for ImageFilter.GaussianBlur(radius=sigma) (BoxBlur.c: _gaussian_blur_radius, then
+    ImagingHorizontalBoxBlur's fixed-point weights), in the float32 / UINT32 arithmetic of the C code.  radius = -1: nothing to blur."""
+    import math
+    import numpy as np
+    f32 = np.float32
+    s = f32(sigma)
+    s2 = f32(s * s / f32(passes))
+    big_l = f32(math.sqrt(12.0 * float(s2) + 1.0))
+    l = f32(math.floor((float(big_l) - 1.0) / 2.0))
+    a = f32((f32(2) * l + f32(1)) * (l * (l + f32(1)) - f32(3) * s2))
+    a = f32(a / f32(f32(6) * (s2 - (l + f32(1)) * (l + f32(1)))))
+    r = f32(l + a)
+    if not r > 0:
+        return -1, 0, 0
+    radius = int(r)
+    ww = int(np.uint32(f32(16777216.0) / f32(r * f32(2) + f32(1))))
+    fw = ((1 << 24) - (radius * 2 + 1) * ww) // 2
+    return radius, ww, fw & 0xFFFFFFFF
+
+
+class DevicePerturber:
+    """PerRowPerturbations (transforms.py:143-203) for a whole uint8 batch on the device: blur (Pillow's box-blur GaussianBlur),
+    brightness / contrast (ImageEnhance blends) and occlusion, each bit for bit what Pillow does to the row's image; "jpeg" rows
+    are a codec round trip and go through `jpeg_fn(frame_u8_hwc_numpy, quality) -> numpy` on the host (none given: an error).
+    Frames are the RESIZED images (the perturbation sits between Resize and ToTensor: transforms.py:249-256)."""
+
+    PASSES = 3  # ImageFilter.GaussianBlur -> ImagingGaussianBlur(..., passes=3)
+
+    def __init__(self, device, key: bytes = DEFAULT_HMAC_KEY, jpeg_fn=None):
+        self.device, self.key, self.jpeg_fn = torch.device(device), key, jpeg_fn
+        self._aug = DeviceAugmenter(device)   # (its staging / scratch helpers)
+
+    def __call__(self, frames: torch.Tensor, rows) -> torch.Tensor:
+        """frames uint8 [B, H, W, 3] on the device, rows: one metadata mapping (or None) per frame.  Returns a new uint8 tensor."""
+        import numpy as np
+        if frames.dtype != torch.uint8 or frames.ndim != 4 or frames.shape[-1] != 3 or not frames.is_contiguous():
+            raise ValueError("frames must be a contiguous uint8 [B, H, W, 3] tensor")
+        if not frames.is_cuda:
+            raise _lib.PolypMaeError("DevicePerturber runs on the GPU only (no CPU fallback)")
+        B, H, W, _ = frames.shape
+        if len(rows) != B:
+            raise ValueError("one row per frame")
+        plans = [perturbation_plan(r, self.key) for r in rows]
+        lib = _lib.load()
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        up, buf = self._aug._upload, self._aug._buf
+        out = frames.clone()
+        kinds = {p[0] for p in plans}
+        if "jpeg" in kinds:
+            if self.jpeg_fn is None:
+                raise _lib.PolypMaeError("a 'jpeg' row needs a host codec: pass jpeg_fn (JPEG re-encoding is not device work)")
+            for i, p in enumerate(plans):
+                if p[0] == "jpeg":
+                    out[i].copy_(torch.from_numpy(np.array(self.jpeg_fn(frames[i].cpu().numpy(), p[1]), dtype=np.uint8)))
+        if "bc" in kinds:
+            jit = np.zeros((B, 8), dtype=np.int32)
+            jit[:, :4] = -1
+            fac = np.ones((B, 3), dtype=np.float32)
+            for i, p in enumerate(plans):
+                if p[0] != "bc":
+                    continue
+                ops = []
+                if p[1] is not None and p[1] > 0:   # transforms.py:92-96: brightness first, then contrast, each only if > 0
+                    ops.append(0)
+                    fac[i, 0] = p[1]
+                if p[2] is not None and p[2] > 0:
+                    ops.append(1)
+                    fac[i, 1] = p[2]
+                jit[i, :len(ops)] = ops
+            jit[:, 4:7] = fac.view(np.int32)
+            src = buf("pt_src", (B, H, W, 3), torch.uint8)
+            src.copy_(out)
+            _lib.check(lib.pm_aug_color_jitter_u8(src.data_ptr(), out.data_ptr(), up("pt_jit", jit).data_ptr(),
+                                                  buf("pt_lsum", (B,), torch.int64).data_ptr(), B, H, W, st), "pm_aug_color_jitter_u8")
+        if "blur" in kinds:
+            prm = np.zeros((B, 3), dtype=np.uint32)
+            prm[:, 0] = np.uint32(0xFFFFFFFF)   # radius -1: pass through
+            for i, p in enumerate(plans):
+                if p[0] == "blur":
+                    r, ww, fw = pil_box_blur_params(p[1], self.PASSES)
+                    prm[i] = (np.uint32(r & 0xFFFFFFFF), ww, fw)
+            tmp = buf("pt_tmp", (B, H, W, 3), torch.uint8)
+            _lib.check(lib.pm_aug_pil_gaussian_blur_u8(out.data_ptr(), tmp.data_ptr(), out.data_ptr(), up("pt_blur", prm.view(np.int32)).data_ptr(),
+                                                       self.PASSES, B, H, W, st), "pm_aug_pil_gaussian_blur_u8")
+        if "occ" in kinds:
+            rects = np.zeros((B, 4), dtype=np.int32)
+            rects[:, 2] = -1   # x1 < x0: nothing
+            for i, p in enumerate(plans):
+                if p[0] == "occ":
+                    r = occlusion_rect(p[1], p[2], W, H)
+                    if r is not None:
+                        rects[i] = r
+            _lib.check(lib.pm_aug_occlude_u8(out.data_ptr(), up("pt_rects", rects).data_ptr(), B, H, W, st), "pm_aug_occlude_u8")
+        return out
+
+
 class DevicePrefetcher:
     """Wraps a loader that yields (frames uint8 [B,H,W,3] on the host, *rest): copies batch i+1 to the device on a
     side stream (pinned staging, two slots) while batch i is consumed, and yields (imgs float32 [B,3,H,W] on the

@@ -173,3 +173,80 @@ def test_random_resized_crop_bicubic_bit_exact(Hs, Ws):
     hflip = torch.tensor([1, 0, 1, 1, 0, 0, 1], dtype=torch.bool)
     t = aug.mae_transform(torch.from_numpy(x).to(DEV), boxes, hflip)
     assert torch.equal(t.cpu(), to_tensor_normalize(torch.from_numpy(want), hflip.to(torch.uint8)))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Eval-time perturbations (classification/data/transforms.py:143-203) on the device
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _pil_jpeg(frame, quality):
+    import io
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(frame).save(buf, format="JPEG", quality=quality, optimize=False, subsampling=0)   # transforms.py:78-85
+    return np.asarray(Image.open(buf).convert("RGB"))
+
+
+def test_device_perturber_equals_the_references_per_row_perturbations(golden):
+    """ssl4polyp_amd.data.DevicePerturber on a batch holding EVERY row of tests/golden/perturb.npz at once (blur, brightness /
+    contrast, occlusion, jpeg through the host hook, clean and silently ignored rows mixed in one batch) against what the REFERENCE's
+    PerRowPerturbations returned for each row (tests/golden/make_perturb_fixtures.py), bit for bit."""
+    import json
+    from ssl4polyp_amd.data import DevicePerturber
+    fx = golden("perturb.npz")
+    rows = json.loads(str(fx["rows"]))
+    pert = DevicePerturber(DEV, jpeg_fn=_pil_jpeg)
+    for name in ("smooth", "noise"):
+        img = fx[f"img/{name}"]
+        idx = [i for i in range(len(rows)) if f"out/{name}/{i}" in fx or f"same/{name}/{i}" in fx]
+        want = np.stack([fx[f"out/{name}/{i}"] if f"out/{name}/{i}" in fx else img for i in idx])
+        frames = torch.from_numpy(np.stack([img] * len(idx))).to(DEV)
+        got = pert(frames, [rows[i] for i in idx]).cpu().numpy()
+        assert torch.equal(frames.cpu(), torch.from_numpy(np.stack([img] * len(idx))))   # the input batch is left alone
+        for j, i in enumerate(idx):
+            assert np.array_equal(got[j], want[j]), (name, i, rows[i])
+
+
+@pytest.mark.parametrize("H,W", [(224, 224), (97, 131), (8, 5)])
+def test_device_perturber_random_rows_equal_the_oracle(H, W):
+    """Rows with drawn parameters at the evaluation size and at awkward sizes (a frame narrower than the blur window) against
+    oracle/augment_ref.py (pinned by the reference's outputs on the CPU side: tests/test_oracle_golden.py)."""
+    from oracle import augment_ref as R
+    from ssl4polyp_amd import data as D
+    rng = np.random.Generator(np.random.PCG64(H * 1000 + W))
+    B = 24
+    x = _frames(B, H, W, 11, smooth=(H % 2 == 0))
+    rows = []
+    for b in range(B):
+        kind = ("blur", "bc", "occ", "clean")[b % 4]
+        row = {"frame_path": f"p/{b}.jpg", "frame_id": b, "case_id": b // 3, "variant": kind, "perturbation_id": kind}
+        if kind == "blur":
+            row["blur_sigma"] = float(rng.uniform(0.05, 7.0))
+        elif kind == "bc":
+            row["brightness"], row["contrast"] = float(rng.uniform(0.3, 1.9)), float(rng.uniform(0.3, 1.9))
+        elif kind == "occ":
+            row["bbox_area_frac"] = float(rng.uniform(0.001, 0.9))
+        rows.append(row)
+    got = D.DevicePerturber(DEV)(torch.from_numpy(x).to(DEV), rows).cpu().numpy()
+    for b, row in enumerate(rows):
+        plan = D.perturbation_plan(row)
+        if plan[0] == "blur":
+            want = R.pil_gaussian_blur(x[b], plan[1])
+        elif plan[0] == "bc":
+            want = R.brightness_contrast(x[b], plan[1], plan[2])
+        elif plan[0] == "occ":
+            want = R.occlude(x[b], D.occlusion_rect(plan[1], plan[2], W, H))
+        else:
+            want = x[b]
+        assert np.array_equal(got[b], want), (b, row)
+
+
+def test_device_perturber_refuses_what_it_cannot_do():
+    from ssl4polyp_amd import _lib
+    from ssl4polyp_amd.data import DevicePerturber
+    x = torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device=DEV)
+    with pytest.raises(_lib.PolypMaeError):
+        DevicePerturber(DEV)(x, [{"variant": "jpeg_30"}])      # no host codec given
+    with pytest.raises(_lib.PolypMaeError):
+        DevicePerturber(DEV)(x.cpu(), [{"variant": "blur_1"}])  # GPU only
+    with pytest.raises(ValueError):
+        DevicePerturber(DEV)(x, [])

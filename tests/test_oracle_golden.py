@@ -201,3 +201,54 @@ def test_bf16_operand_rounding_alone_explains_the_bf16_tolerance(golden):
         loss, _, mask = Sim.mae_forward(sdm, imgs, noise, cfg)
     assert abs(loss.item() - float(fxm["loss"])) / float(fxm["loss"]) < 1e-3
     np.testing.assert_array_equal(mask.numpy(), fxm["mask"])
+
+
+def _perturb_cases(golden):
+    fx = golden("perturb.npz")
+    rows = json.loads(str(fx["rows"]))
+    for name in ("smooth", "noise"):
+        img = fx[f"img/{name}"]
+        for i, row in enumerate(rows):
+            if f"out/{name}/{i}" in fx:
+                yield name, i, row, img, fx[f"out/{name}/{i}"]
+            elif f"same/{name}/{i}" in fx:
+                yield name, i, row, img, img
+
+
+def test_perturbation_plan_and_oracle_vs_reference(golden):
+    """Eval-time perturbations (classification/data/transforms.py:143-203): the product's host-side plan (which perturbation, which
+    parameters, which HMAC / rng_seed-seeded rectangle) followed by the oracle's pixel arithmetic (Pillow's box-blur GaussianBlur,
+    the ImageEnhance blends, the inclusive rectangle) equals what the REFERENCE's PerRowPerturbations returned, bit for bit -- for
+    every row of tests/golden/perturb.npz, the silently ignored spellings included.  JPEG rows go through Pillow's codec here."""
+    import io
+    from PIL import Image
+    from oracle import augment_ref as R
+    from ssl4polyp_amd import data as D
+    fx = golden("perturb.npz")
+    rows = json.loads(str(fx["rows"]))
+    for i, row in enumerate(rows):
+        assert D._row_seed(row, D.DEFAULT_HMAC_KEY) == int(fx[f"seed/{i}"]), row
+    kinds = set()
+    for name, i, row, img, want in _perturb_cases(golden):
+        plan = D.perturbation_plan(row)
+        kinds.add(plan[0])
+        if plan[0] == "none":
+            got = img
+        elif plan[0] == "blur":
+            got = R.pil_gaussian_blur(img, plan[1])
+        elif plan[0] == "bc":
+            got = R.brightness_contrast(img, plan[1], plan[2])
+        elif plan[0] == "occ":
+            got = R.occlude(img, D.occlusion_rect(plan[1], plan[2], img.shape[1], img.shape[0]))
+        else:
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, format="JPEG", quality=plan[1], optimize=False, subsampling=0)
+            got = np.asarray(Image.open(buf).convert("RGB"))
+        assert np.array_equal(got, want), (name, i, row, plan)
+    assert kinds == {"none", "blur", "bc", "occ", "jpeg"}
+    # the box-blur weights the device kernel receives are the oracle's
+    for sigma in (0.001, 0.5, 1.0, 1.5, 2.25, 3.0, 6.5, 10.0):
+        r = R.pil_gaussian_box_radius(sigma)
+        radius, ww, fw = D.pil_box_blur_params(sigma)
+        assert radius == int(r) and ww == int(np.uint32(np.float32(16777216.0) / np.float32(r * np.float32(2) + np.float32(1))))
+        assert fw == ((1 << 24) - (2 * radius + 1) * ww) // 2
