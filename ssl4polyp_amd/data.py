@@ -440,6 +440,18 @@ class DevicePerturber:
         self.device, self.key, self.jpeg_fn = torch.device(device), key, jpeg_fn
         self._aug = DeviceAugmenter(device)   # (its staging / scratch helpers)
 
+    def eval_transform(self, frames: torch.Tensor, rows=None, size: int = 224, mean: Sequence[float] = IMAGENET_MEAN,
+                       std: Sequence[float] = IMAGENET_STD) -> torch.Tensor:
+        """ClassificationTransforms(stage="val" / "test", enable_perturbations=rows is not None) for a decoded uint8 batch
+        [B, Hs, Ws, 3] of one frame size (transforms.py:234-256): Resize((size, size)) -> [the rows' perturbations] -> ToTensor ->
+        Normalize, f32 [B, 3, size, size] out; three to ten launches, nothing leaves the device."""
+        if self._aug.size != size:
+            self._aug = DeviceAugmenter(self.device, size=size)
+        x = self._aug.resize(frames)
+        if rows is not None:
+            x = self(x, rows)
+        return preprocess_u8(x, None, mean, std)
+
     def __call__(self, frames: torch.Tensor, rows) -> torch.Tensor:
         """frames uint8 [B, H, W, 3] on the device, rows: one metadata mapping (or None) per frame.  Returns a new uint8 tensor."""
         import numpy as np

@@ -250,3 +250,30 @@ def test_device_perturber_refuses_what_it_cannot_do():
         DevicePerturber(DEV)(x.cpu(), [{"variant": "blur_1"}])  # GPU only
     with pytest.raises(ValueError):
         DevicePerturber(DEV)(x, [])
+
+
+def test_eval_transform_is_resize_perturb_to_tensor_normalize():
+    """ClassificationTransforms(stage="test", enable_perturbations=True) as one device pipeline (transforms.py:234-256) against the
+    oracle's stages composed on the CPU: uint8 stages bit for bit, the f32 output equal to the oracle's ToTensor + Normalize."""
+    from oracle import augment_ref as R
+    from oracle import input_ref as I
+    from ssl4polyp_amd import data as D
+    x = _frames(6, 180, 240, 21)
+    rows = [{"variant": v, "frame_id": i} for i, v in enumerate(("blur_1p5", "clean", "bc_b1p3_c0p7", "occ_a0p2", "blur_0p5", "occ_0p01"))]
+    got = D.DevicePerturber(DEV).eval_transform(torch.from_numpy(x).to(DEV), rows)
+    r = R.resize_bilinear(x, 224, 224)
+    stages = []
+    for b, row in enumerate(rows):
+        plan = D.perturbation_plan(row)
+        img = r[b]
+        if plan[0] == "blur":
+            img = R.pil_gaussian_blur(img, plan[1])
+        elif plan[0] == "bc":
+            img = R.brightness_contrast(img, plan[1], plan[2])
+        elif plan[0] == "occ":
+            img = R.occlude(img, D.occlusion_rect(plan[1], plan[2], 224, 224))
+        stages.append(img)
+    want = I.to_tensor_normalize(torch.from_numpy(np.stack(stages)))
+    assert got.shape == (6, 3, 224, 224) and torch.equal(got.cpu(), want)
+    plain = D.DevicePerturber(DEV).eval_transform(torch.from_numpy(x).to(DEV))
+    assert torch.equal(plain.cpu(), I.to_tensor_normalize(torch.from_numpy(r)))
