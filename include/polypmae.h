@@ -297,8 +297,14 @@ int pm_aug_geometry_u8(const unsigned char* src, const pm_aug_geom* geom, void* 
  *            with r = _gaussian_blur_radius(sigma, passes) in float32 (built by the caller: data.py pil_box_blur_params);
  *            radius < 0: the sample passes through unchanged.  tmp: u8 [B][H][W][3] scratch; src may equal dst, tmp must not.
  *   "occ*":  ImageDraw.rectangle([x0, y0, x1, y1], fill=0), corners inclusive, clipped to the frame; x1 < x0: nothing.  In place.
- *   "bc*":   pm_aug_color_jitter_u8 with order {0, 1, -1, -1}.      "jpeg*": a codec round trip; host side, like decoding.
- * Bit for bit against oracle/augment_ref.py, which is pinned by running the reference's own PerRowPerturbations (Pillow 12.2). */
+ *   "bc*":   pm_aug_color_jitter_u8 with order {0, 1, -1, -1}.
+ *   "jpeg*": img.save(format="JPEG", quality=q, optimize=False, subsampling=0) and back (transforms.py:78-85) WITHOUT a bitstream:
+ *            entropy coding is lossless, so the round trip is libjpeg's integer pipeline -- RGB -> YCbCr (jccolor.c), 4:4:4, islow
+ *            forward DCT (jfdctint.c), Annex-K tables scaled by q (jcparam.c, baseline), quantise / dequantise (jcdctmgr.c), islow
+ *            inverse DCT (jidctint.c), YCbCr -> RGB (jdcolor.c); sides that are not multiples of 8 are edge-replicated and cropped.
+ *            quality: int [B], 1..100; <= 0: the sample is copied.  src may equal dst.
+ * Bit for bit against oracle/augment_ref.py, which is pinned by running the reference's own PerRowPerturbations (Pillow 12.2 with
+ * its bundled libjpeg-turbo). */
 typedef struct pm_aug_boxblur {
   int radius;
   unsigned int ww, fw;
@@ -306,6 +312,7 @@ typedef struct pm_aug_boxblur {
 int pm_aug_pil_gaussian_blur_u8(const unsigned char* src, unsigned char* tmp, unsigned char* dst, const pm_aug_boxblur* prm,
                                 int passes, int B, int H, int W, void* stream);
 int pm_aug_occlude_u8(unsigned char* img, const int* rects, int B, int H, int W, void* stream);
+int pm_aug_jpeg_roundtrip_u8(const unsigned char* src, unsigned char* dst, const int* quality, int B, int H, int W, void* stream);
 
 /* One transformer block forward for one range of samples in ONE call (timm Block: models_mae.py:39-41,53-55,166-167,
  * 186-187; models.py:122-123,204-205):  x_mid = x + proj(attn(LN1 x));  x_out = x_mid + fc2(gelu(fc1(LN2 x_mid))).

@@ -381,3 +381,90 @@ def brightness_contrast(img: np.ndarray, brightness, contrast) -> np.ndarray:
     if contrast is not None and contrast > 0:
         out = adjust_contrast(out[None], contrast)[0]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "jpeg" rows (transforms.py:78-85): img.save(buffer, format="JPEG", quality=q, optimize=False, subsampling=0), Image.open, convert.
+# Entropy coding is lossless, so what comes back is libjpeg's integer pipeline and nothing else -- restated here without a bitstream:
+#   jccolor.c   RGB -> YCbCr, 16-bit fixed point;  4:4:4 (subsampling=0)
+#   jfdctint.c  "islow" forward DCT (Loeffler-Ligtenberg-Moschytz; CONST_BITS 13, PASS1_BITS 2; output scaled by 8)
+#   jcparam.c   Annex-K tables scaled by the quality: 5000 / q below 50, 200 - 2 q from 50 on; (t * s + 50) / 100, baseline clamp 1..255
+#   jcdctmgr.c  quantise with divisor (q << 3), round half away from zero;  jdcoefct / jddctmgr: coefficient * q
+#   jidctint.c  islow inverse DCT, + 128, clamp;  jdcolor.c YCbCr -> RGB through its fixed-point tables
+# Sides that are not multiples of 8 are padded by edge replication (jcprepct.c) and cropped.  PINNED by the jpeg rows of
+# tests/golden/perturb.npz (made by the reference's own _apply_jpeg through PerRowPerturbations; Pillow 12.2 + its libjpeg-turbo).
+# ---------------------------------------------------------------------------------------------------------------------
+_JPEG_LUM = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                      18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101,
+                      72, 92, 95, 98, 112, 100, 103, 99], dtype=np.int64).reshape(8, 8)
+_JPEG_CHR = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99]
+                     + [99] * 32, dtype=np.int64).reshape(8, 8)
+_JC = dict(a=2446, b=3196, c=4433, d=6270, e=7373, f=9633, g=12299, h=15137, i=16069, j=16819, k=20995, l=25172)
+
+
+def _jdescale(x, n):
+    return (x + (1 << (n - 1))) >> n
+
+
+def _jfdct8(d, first):
+    d0, d1, d2, d3, d4, d5, d6, d7 = (d[..., i] for i in range(8))
+    t0, t7, t1, t6, t2, t5, t3, t4 = d0 + d7, d0 - d7, d1 + d6, d1 - d6, d2 + d5, d2 - d5, d3 + d4, d3 - d4
+    t10, t13, t11, t12 = t0 + t3, t0 - t3, t1 + t2, t1 - t2
+    sh = 11 if first else 15
+    o = [None] * 8
+    o[0] = (t10 + t11) << 2 if first else _jdescale(t10 + t11, 2)
+    o[4] = (t10 - t11) << 2 if first else _jdescale(t10 - t11, 2)
+    z1 = (t12 + t13) * _JC["c"]
+    o[2] = _jdescale(z1 + t13 * _JC["d"], sh)
+    o[6] = _jdescale(z1 - t12 * _JC["h"], sh)
+    z1, z2, z3, z4 = t4 + t7, t5 + t6, t4 + t6, t5 + t7
+    z5 = (z3 + z4) * _JC["f"]
+    a4, a5, a6, a7 = t4 * _JC["a"], t5 * _JC["j"], t6 * _JC["l"], t7 * _JC["g"]
+    z1, z2, z3, z4 = -z1 * _JC["e"], -z2 * _JC["k"], -z3 * _JC["i"] + z5, -z4 * _JC["b"] + z5
+    o[7], o[5], o[3], o[1] = (_jdescale(a4 + z1 + z3, sh), _jdescale(a5 + z2 + z4, sh), _jdescale(a6 + z2 + z3, sh),
+                              _jdescale(a7 + z1 + z4, sh))
+    return np.stack(o, -1)
+
+
+def _jidct8(c, first):
+    i0, i1, i2, i3, i4, i5, i6, i7 = (c[..., i] for i in range(8))
+    z1 = (i2 + i6) * _JC["c"]
+    e2, e3 = z1 - i6 * _JC["h"], z1 + i2 * _JC["d"]
+    e0, e1 = (i0 + i4) << 13, (i0 - i4) << 13
+    t10, t13, t11, t12 = e0 + e3, e0 - e3, e1 + e2, e1 - e2
+    o0, o1, o2, o3 = i7, i5, i3, i1
+    z1, z2, z3, z4 = o0 + o3, o1 + o2, o0 + o2, o1 + o3
+    z5 = (z3 + z4) * _JC["f"]
+    o0, o1, o2, o3 = o0 * _JC["a"], o1 * _JC["j"], o2 * _JC["l"], o3 * _JC["g"]
+    z1, z2, z3, z4 = -z1 * _JC["e"], -z2 * _JC["k"], -z3 * _JC["i"] + z5, -z4 * _JC["b"] + z5
+    o0, o1, o2, o3 = o0 + z1 + z3, o1 + z2 + z4, o2 + z2 + z3, o3 + z1 + z4
+    sh = 11 if first else 18
+    return np.stack([_jdescale(t10 + o3, sh), _jdescale(t11 + o2, sh), _jdescale(t12 + o1, sh), _jdescale(t13 + o0, sh),
+                     _jdescale(t13 - o0, sh), _jdescale(t12 - o1, sh), _jdescale(t11 - o2, sh), _jdescale(t10 - o3, sh)], -1)
+
+
+def jpeg_roundtrip(img: np.ndarray, quality: int) -> np.ndarray:
+    """uint8 [H, W, 3] through a baseline 4:4:4 JPEG of the given quality and back, as Pillow (libjpeg-turbo) returns it."""
+    q = max(1, min(100, int(quality)))
+    scale = 5000 // q if q < 50 else 200 - 2 * q
+    H, W, _ = img.shape
+    Hp, Wp = (H + 7) // 8 * 8, (W + 7) // 8 * 8
+    x = np.pad(img, ((0, Hp - H), (0, Wp - W), (0, 0)), mode="edge").astype(np.int64)
+    r, g, b = x[..., 0], x[..., 1], x[..., 2]
+    comps = ((19595 * r + 38470 * g + 7471 * b + 32768) >> 16,
+             (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16,
+             (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16)
+    rec = []
+    for comp, base in zip(comps, (_JPEG_LUM, _JPEG_CHR, _JPEG_CHR)):
+        qt = np.clip((base * scale + 50) // 100, 1, 255)
+        blk = comp.reshape(Hp // 8, 8, Wp // 8, 8).transpose(0, 2, 1, 3) - 128
+        d = _jfdct8(blk, True)                                              # rows
+        d = np.swapaxes(_jfdct8(np.swapaxes(d, -1, -2), False), -1, -2)     # columns
+        qv = qt << 3
+        qc = (np.abs(d) + (qv >> 1)) // qv
+        coef = np.where(d < 0, -qc, qc) * qt
+        ws = np.swapaxes(_jidct8(np.swapaxes(coef, -1, -2), True), -1, -2)  # columns
+        rec.append(np.clip(_jidct8(ws, False) + 128, 0, 255).transpose(0, 2, 1, 3).reshape(Hp, Wp))
+    y, cb, cr = rec[0], rec[1] - 128, rec[2] - 128
+    out = np.stack([y + ((91881 * cr + 32768) >> 16), y + ((-22554 * cb + 32768 - 46802 * cr) >> 16), y + ((116130 * cb + 32768) >> 16)], -1)
+    return np.clip(out, 0, 255).astype(np.uint8)[:H, :W]

@@ -9,8 +9,8 @@ dev = torch.device("cuda", 0)
 B = 256
 x = np.random.Generator(np.random.PCG64(1)).integers(0, 256, (B, 224, 224, 3), dtype=np.uint8)
 for kind, mk in (("blur sigma 2", lambda b: {"variant": "blur_2"}), ("bc 1.2 / 0.8", lambda b: {"variant": "bc_b1p2_c0p8"}),
-                 ("occ 0.15", lambda b: {"variant": "occ_a0p15", "frame_id": b}),
-                 ("mixed", lambda b: [{"variant": "blur_2"}, {"variant": "bc_b1p2_c0p8"}, {"variant": "occ_a0p15", "frame_id": b}, {"variant": "clean"}][b % 4])):
+                 ("occ 0.15", lambda b: {"variant": "occ_a0p15", "frame_id": b}), ("jpeg 30", lambda b: {"variant": "jpeg_30"}),
+                 ("mixed", lambda b: [{"variant": "blur_2"}, {"variant": "bc_b1p2_c0p8"}, {"variant": "occ_a0p15", "frame_id": b}, {"variant": "clean"}, {"variant": "jpeg_30"}][b % 5])):
     rows = [mk(b) for b in range(B)]
     pert = D.DevicePerturber(dev)
     xd = torch.from_numpy(x).to(dev)
@@ -26,6 +26,9 @@ for kind, mk in (("blur sigma 2", lambda b: {"variant": "blur_2"}), ("bc 1.2 / 0
         if p[0] == "blur": im = im.filter(ImageFilter.GaussianBlur(radius=p[1]))
         elif p[0] == "bc":
             im = ImageEnhance.Brightness(im).enhance(p[1]); im = ImageEnhance.Contrast(im).enhance(p[2])
+        elif p[0] == "jpeg":
+            import io
+            buf = io.BytesIO(); im.save(buf, format="JPEG", quality=p[1], optimize=False, subsampling=0); buf.seek(0); im = Image.open(buf).convert("RGB")
         elif p[0] == "occ":
             r = D.occlusion_rect(p[1], p[2], 224, 224); im = im.copy(); ImageDraw.Draw(im).rectangle(list(r), fill=(0, 0, 0))
         np.asarray(im)

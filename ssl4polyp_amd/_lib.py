@@ -54,6 +54,7 @@ SIGNATURES = {
     "pm_aug_geometry_u8": [P, P, P, I, I, I, I, F, F, F, F, F, F, P],
     "pm_aug_pil_gaussian_blur_u8": [P, P, P, P, I, I, I, I, P],
     "pm_aug_occlude_u8": [P, P, I, I, I, P],
+    "pm_aug_jpeg_roundtrip_u8": [P, P, P, I, I, I, P],
     "pm_comm_unique_id": [P],
     "pm_comm_create": [P, P, I, I],
     "pm_comm_world": [P, P, P],
@@ -73,7 +74,7 @@ SIGNATURES = {
     "pm_dgelu": [P, P, P, I, L, P],
 }
 
-ABI_VERSION = 12  # pm_abi_version() of the library these signatures describe
+ABI_VERSION = 13  # pm_abi_version() of the library these signatures describe
 PM_GROUP_WHOLE_K = -1  # pm_wgrad_group(max_blocks=...): never slice, whole-K 256x256 tiles
 
 WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4

@@ -439,6 +439,159 @@ __global__ __launch_bounds__(256) void occlude_kernel(unsigned char* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "jpeg*" rows: img.save(format="JPEG", quality=q, optimize=False, subsampling=0) and back (transforms.py:78-85).  The pixels
+// that come back do not depend on the entropy coding (lossless) but on libjpeg's integer pipeline only, which is restated here step
+// for step -- no bitstream is ever produced:  RGB -> YCbCr in 16-bit fixed point (jccolor.c), 4:4:4 (no subsampling), per 8 x 8
+// block the "islow" forward DCT (jfdctint.c: Loeffler-Ligtenberg-Moschytz, CONST_BITS 13, PASS1_BITS 2, output scaled by 8),
+// quantisation by the Annex-K tables scaled by the quality (jcparam.c: 5000 / q below 50, 200 - 2 q above; baseline clamp 1..255)
+// with the divisor << 3 and round-half-away (jcdctmgr.c), dequantisation, the islow inverse DCT (jidctint.c) with its range limit,
+// YCbCr -> RGB through the fixed-point tables of jdcolor.c.  Frames whose sides are not multiples of 8 are padded by replicating
+// the last column / row (jcprepct.c expand edges) and cropped again.  One thread per 8 x 8 block, all three components.
+// ---------------------------------------------------------------------------------------------
+__device__ const unsigned char kStdLum[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+                                              14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+                                              18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                                              49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+__device__ const unsigned char kStdChr[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99,
+                                              24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                                              99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                              99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+constexpr int kF0298 = 2446, kF0390 = 3196, kF0541 = 4433, kF0765 = 6270, kF0899 = 7373, kF1175 = 9633, kF1501 = 12299, kF1847 = 15137,
+              kF1961 = 16069, kF2053 = 16819, kF2562 = 20995, kF3072 = 25172;
+__device__ __forceinline__ int jdescale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// one 8-point forward pass of jfdctint.c on d[0], d[s], ..., d[7 s] (first: rows, output << PASS1_BITS; second: columns)
+__device__ __forceinline__ void jfdct8(int* d, int s, bool first) {
+  const int t0 = d[0] + d[7 * s], t7 = d[0] - d[7 * s], t1 = d[s] + d[6 * s], t6 = d[s] - d[6 * s];
+  const int t2 = d[2 * s] + d[5 * s], t5 = d[2 * s] - d[5 * s], t3 = d[3 * s] + d[4 * s], t4 = d[3 * s] - d[4 * s];
+  const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+  const int sh = first ? 13 - 2 : 13 + 2;
+  d[0] = first ? (t10 + t11) << 2 : jdescale(t10 + t11, 2);
+  d[4 * s] = first ? (t10 - t11) << 2 : jdescale(t10 - t11, 2);
+  int z1 = (t12 + t13) * kF0541;
+  d[2 * s] = jdescale(z1 + t13 * kF0765, sh);
+  d[6 * s] = jdescale(z1 + t12 * (-kF1847), sh);
+  z1 = t4 + t7;
+  int z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+  const int z5 = (z3 + z4) * kF1175;
+  const int a4 = t4 * kF0298, a5 = t5 * kF2053, a6 = t6 * kF3072, a7 = t7 * kF1501;
+  z1 *= -kF0899;
+  z2 *= -kF2562;
+  z3 = z3 * -kF1961 + z5;
+  z4 = z4 * -kF0390 + z5;
+  d[7 * s] = jdescale(a4 + z1 + z3, sh);
+  d[5 * s] = jdescale(a5 + z2 + z4, sh);
+  d[3 * s] = jdescale(a6 + z2 + z3, sh);
+  d[s] = jdescale(a7 + z1 + z4, sh);
+}
+// one 8-point inverse pass of jidctint.c (first: columns, descale CONST_BITS - PASS1_BITS; second: rows, + 3 more bits)
+__device__ __forceinline__ void jidct8(int* c, int s, bool first) {
+  int z2 = c[2 * s], z3 = c[6 * s];
+  int z1 = (z2 + z3) * kF0541;
+  const int e2 = z1 + z3 * (-kF1847), e3 = z1 + z2 * kF0765;
+  z2 = c[0];
+  z3 = c[4 * s];
+  const int e0 = (z2 + z3) << 13, e1 = (z2 - z3) << 13;
+  const int t10 = e0 + e3, t13 = e0 - e3, t11 = e1 + e2, t12 = e1 - e2;
+  int o0 = c[7 * s], o1 = c[5 * s], o2 = c[3 * s], o3 = c[s];
+  z1 = o0 + o3;
+  z2 = o1 + o2;
+  z3 = o0 + o2;
+  int z4 = o1 + o3;
+  const int z5 = (z3 + z4) * kF1175;
+  o0 *= kF0298;
+  o1 *= kF2053;
+  o2 *= kF3072;
+  o3 *= kF1501;
+  z1 *= -kF0899;
+  z2 *= -kF2562;
+  z3 = z3 * -kF1961 + z5;
+  z4 = z4 * -kF0390 + z5;
+  o0 += z1 + z3;
+  o1 += z2 + z4;
+  o2 += z2 + z3;
+  o3 += z1 + z4;
+  const int sh = first ? 13 - 2 : 13 + 2 + 3;
+  c[0] = jdescale(t10 + o3, sh);
+  c[7 * s] = jdescale(t10 - o3, sh);
+  c[s] = jdescale(t11 + o2, sh);
+  c[6 * s] = jdescale(t11 - o2, sh);
+  c[2 * s] = jdescale(t12 + o1, sh);
+  c[5 * s] = jdescale(t12 - o1, sh);
+  c[3 * s] = jdescale(t13 + o0, sh);
+  c[4 * s] = jdescale(t13 - o0, sh);
+}
+
+// quality: int [B]; <= 0: the sample is copied.  In place is fine (a thread reads and writes its own block only).
+__global__ __launch_bounds__(64) void jpeg_roundtrip_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                            const int* __restrict__ quality, int B, int H, int W) {
+  const int bw = (W + 7) >> 3, bh = (H + 7) >> 3;
+  const long total = (long)B * bh * bw;
+  for (long id = (long)blockIdx.x * 64 + threadIdx.x; id < total; id += (long)gridDim.x * 64) {
+    const int b = id / ((long)bh * bw), rem = id % ((long)bh * bw);
+    const int by = rem / bw, bx = rem % bw;
+    const unsigned char* img = src + (long)b * H * W * 3;
+    unsigned char* out = dst + (long)b * H * W * 3;
+    int q = quality[b];
+    if (q <= 0) {
+      for (int i = 0; i < 64; ++i) {
+        const int y = by * 8 + (i >> 3), x = bx * 8 + (i & 7);
+        if (y < H && x < W)
+          for (int c = 0; c < 3; ++c) out[((long)y * W + x) * 3 + c] = img[((long)y * W + x) * 3 + c];
+      }
+      continue;
+    }
+    q = q > 100 ? 100 : q;
+    const int scale = q < 50 ? 5000 / q : 200 - q * 2;
+    unsigned char rec[3][64];
+    for (int comp = 0; comp < 3; ++comp) {
+      int v[64];
+      for (int i = 0; i < 64; ++i) {
+        int y = by * 8 + (i >> 3), x = bx * 8 + (i & 7);
+        y = y < H ? y : H - 1;  // edge replication
+        x = x < W ? x : W - 1;
+        const unsigned char* p = img + ((long)y * W + x) * 3;
+        const int r = p[0], g = p[1], bl = p[2];
+        int s;
+        if (comp == 0) s = (19595 * r + 38470 * g + 7471 * bl + 32768) >> 16;
+        else if (comp == 1) s = (-11059 * r - 21709 * g + 32768 * bl + (128 << 16) + 32767) >> 16;
+        else s = (32768 * r - 27439 * g - 5329 * bl + (128 << 16) + 32767) >> 16;
+        v[i] = s - 128;
+      }
+      for (int r = 0; r < 8; ++r) jfdct8(v + 8 * r, 1, true);
+      for (int c = 0; c < 8; ++c) jfdct8(v + c, 8, false);
+      const unsigned char* base = comp == 0 ? kStdLum : kStdChr;
+      for (int i = 0; i < 64; ++i) {
+        int qt = ((int)base[i] * scale + 50) / 100;
+        qt = qt < 1 ? 1 : (qt > 255 ? 255 : qt);
+        const int qv = qt << 3, d = v[i];
+        const int a = d < 0 ? -d : d;
+        const int qc = (a + (qv >> 1)) / qv;
+        v[i] = (d < 0 ? -qc : qc) * qt;   // quantise, dequantise
+      }
+      for (int c = 0; c < 8; ++c) jidct8(v + c, 8, true);
+      for (int r = 0; r < 8; ++r) jidct8(v + 8 * r, 1, false);
+      for (int i = 0; i < 64; ++i) {
+        const int s = v[i] + 128;
+        rec[comp][i] = (unsigned char)(s < 0 ? 0 : (s > 255 ? 255 : s));
+      }
+    }
+    for (int i = 0; i < 64; ++i) {
+      const int y = by * 8 + (i >> 3), x = bx * 8 + (i & 7);
+      if (y >= H || x >= W) continue;
+      const int yy = rec[0][i], cb = (int)rec[1][i] - 128, cr = (int)rec[2][i] - 128;
+      int r = yy + ((91881 * cr + 32768) >> 16);
+      int g = yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+      int bl = yy + ((116130 * cb + 32768) >> 16);
+      unsigned char* o = out + ((long)y * W + x) * 3;
+      o[0] = (unsigned char)(r < 0 ? 0 : (r > 255 ? 255 : r));
+      o[1] = (unsigned char)(g < 0 ? 0 : (g > 255 ? 255 : g));
+      o[2] = (unsigned char)(bl < 0 ? 0 : (bl > 255 ? 255 : bl));
+    }
+  }
+}
+
 }  // namespace
 
 static_assert(sizeof(Jitter) == sizeof(pm_aug_jitter), "pm_aug_jitter layout");
@@ -568,5 +721,16 @@ extern "C" int pm_aug_occlude_u8(unsigned char* img, const int* rects, int B, in
   if (!img || !rects) return PM_EINVAL;
   if (B <= 0 || H <= 0 || W <= 0) return PM_ESHAPE;
   hipLaunchKernelGGL(occlude_kernel, dim3(64, B), dim3(256), 0, pm_stream(stream), img, rects, B, H, W);
+  return pm_check_launch();
+}
+
+extern "C" int pm_aug_jpeg_roundtrip_u8(const unsigned char* src, unsigned char* dst, const int* quality, int B, int H, int W,
+                                        void* stream) {
+  if (!src || !dst || !quality) return PM_EINVAL;
+  if (B <= 0 || H <= 0 || W <= 0) return PM_ESHAPE;
+  const long blocks = (long)B * ((H + 7) / 8) * ((W + 7) / 8);
+  long grid = (blocks + 63) / 64;
+  grid = grid > 65535 ? 65535 : grid;
+  hipLaunchKernelGGL(jpeg_roundtrip_kernel, dim3((int)grid), dim3(64), 0, pm_stream(stream), src, dst, quality, B, H, W);
   return pm_check_launch();
 }

@@ -573,7 +573,7 @@ extern "C" const char* pm_strerror(int status) {
 
 // 3: pm_gemm_ex / pm_gemm_opts replace pm_tune, workspace queries, pm_vit_head_*, pm_supervised_loss_fwd, pm_scale
 // 10: PM_F16 (precision mode fp16), pm_loss_scale_update, pm_dgelu
-extern "C" int pm_abi_version(void) { return 12; }
+extern "C" int pm_abi_version(void) { return 13; }
 
 extern "C" size_t pm_workspace_bytes(int kind, int M, int N) {
   if (M <= 0 || N <= 0) return 0;

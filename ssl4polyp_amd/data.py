@@ -430,8 +430,9 @@ def pil_box_blur_params(sigma: float, passes: int = 3):
 
 class DevicePerturber:
     """PerRowPerturbations (transforms.py:143-203) for a whole uint8 batch on the device: blur (Pillow's box-blur GaussianBlur),
-    brightness / contrast (ImageEnhance blends) and occlusion, each bit for bit what Pillow does to the row's image; "jpeg" rows
-    are a codec round trip and go through `jpeg_fn(frame_u8_hwc_numpy, quality) -> numpy` on the host (none given: an error).
+    brightness / contrast (ImageEnhance blends), occlusion and the JPEG round trip (libjpeg's integer pipeline without a bitstream:
+    the entropy coding is lossless), each bit for bit what Pillow returns for the row's image.  `jpeg_fn(frame_u8_hwc_numpy, quality)
+    -> numpy`, when given, replaces the device JPEG stage by a host codec (A/B and other codecs).
     Frames are the RESIZED images (the perturbation sits between Resize and ToTensor: transforms.py:249-256)."""
 
     PASSES = 3  # ImageFilter.GaussianBlur -> ImagingGaussianBlur(..., passes=3)
@@ -469,11 +470,14 @@ class DevicePerturber:
         out = frames.clone()
         kinds = {p[0] for p in plans}
         if "jpeg" in kinds:
-            if self.jpeg_fn is None:
-                raise _lib.PolypMaeError("a 'jpeg' row needs a host codec: pass jpeg_fn (JPEG re-encoding is not device work)")
-            for i, p in enumerate(plans):
-                if p[0] == "jpeg":
-                    out[i].copy_(torch.from_numpy(np.array(self.jpeg_fn(frames[i].cpu().numpy(), p[1]), dtype=np.uint8)))
+            if self.jpeg_fn is not None:
+                for i, p in enumerate(plans):
+                    if p[0] == "jpeg":
+                        out[i].copy_(torch.from_numpy(np.array(self.jpeg_fn(frames[i].cpu().numpy(), p[1]), dtype=np.uint8)))
+            else:
+                qual = np.array([p[1] if p[0] == "jpeg" else 0 for p in plans], dtype=np.int32)   # 0: the sample is copied
+                _lib.check(lib.pm_aug_jpeg_roundtrip_u8(out.data_ptr(), out.data_ptr(), up("pt_jpeg", qual).data_ptr(), B, H, W, st),
+                           "pm_aug_jpeg_roundtrip_u8")
         if "bc" in kinds:
             jit = np.zeros((B, 8), dtype=np.int32)
             jit[:, :4] = -1

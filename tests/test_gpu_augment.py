@@ -188,14 +188,15 @@ def _pil_jpeg(frame, quality):
 
 def test_device_perturber_equals_the_references_per_row_perturbations(golden):
     """ssl4polyp_amd.data.DevicePerturber on a batch holding EVERY row of tests/golden/perturb.npz at once (blur, brightness /
-    contrast, occlusion, jpeg through the host hook, clean and silently ignored rows mixed in one batch) against what the REFERENCE's
-    PerRowPerturbations returned for each row (tests/golden/make_perturb_fixtures.py), bit for bit."""
+    contrast, occlusion, the JPEG round trip, clean and silently ignored rows mixed in one batch; a frame whose sides are not
+    multiples of 8 included) against what the REFERENCE's PerRowPerturbations returned for each row
+    (tests/golden/make_perturb_fixtures.py), bit for bit."""
     import json
     from ssl4polyp_amd.data import DevicePerturber
     fx = golden("perturb.npz")
     rows = json.loads(str(fx["rows"]))
-    pert = DevicePerturber(DEV, jpeg_fn=_pil_jpeg)
-    for name in ("smooth", "noise"):
+    pert = DevicePerturber(DEV)
+    for name in ("smooth", "noise", "odd"):
         img = fx[f"img/{name}"]
         idx = [i for i in range(len(rows)) if f"out/{name}/{i}" in fx or f"same/{name}/{i}" in fx]
         want = np.stack([fx[f"out/{name}/{i}"] if f"out/{name}/{i}" in fx else img for i in idx])
@@ -217,7 +218,7 @@ def test_device_perturber_random_rows_equal_the_oracle(H, W):
     x = _frames(B, H, W, 11, smooth=(H % 2 == 0))
     rows = []
     for b in range(B):
-        kind = ("blur", "bc", "occ", "clean")[b % 4]
+        kind = ("blur", "bc", "occ", "clean", "jpeg")[b % 5]
         row = {"frame_path": f"p/{b}.jpg", "frame_id": b, "case_id": b // 3, "variant": kind, "perturbation_id": kind}
         if kind == "blur":
             row["blur_sigma"] = float(rng.uniform(0.05, 7.0))
@@ -225,6 +226,8 @@ def test_device_perturber_random_rows_equal_the_oracle(H, W):
             row["brightness"], row["contrast"] = float(rng.uniform(0.3, 1.9)), float(rng.uniform(0.3, 1.9))
         elif kind == "occ":
             row["bbox_area_frac"] = float(rng.uniform(0.001, 0.9))
+        elif kind == "jpeg":
+            row["jpeg_q"] = int(rng.integers(1, 101))
         rows.append(row)
     got = D.DevicePerturber(DEV)(torch.from_numpy(x).to(DEV), rows).cpu().numpy()
     for b, row in enumerate(rows):
@@ -235,6 +238,8 @@ def test_device_perturber_random_rows_equal_the_oracle(H, W):
             want = R.brightness_contrast(x[b], plan[1], plan[2])
         elif plan[0] == "occ":
             want = R.occlude(x[b], D.occlusion_rect(plan[1], plan[2], W, H))
+        elif plan[0] == "jpeg":
+            want = R.jpeg_roundtrip(x[b], plan[1])
         else:
             want = x[b]
         assert np.array_equal(got[b], want), (b, row)
@@ -244,8 +249,6 @@ def test_device_perturber_refuses_what_it_cannot_do():
     from ssl4polyp_amd import _lib
     from ssl4polyp_amd.data import DevicePerturber
     x = torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device=DEV)
-    with pytest.raises(_lib.PolypMaeError):
-        DevicePerturber(DEV)(x, [{"variant": "jpeg_30"}])      # no host codec given
     with pytest.raises(_lib.PolypMaeError):
         DevicePerturber(DEV)(x.cpu(), [{"variant": "blur_1"}])  # GPU only
     with pytest.raises(ValueError):
@@ -277,3 +280,15 @@ def test_eval_transform_is_resize_perturb_to_tensor_normalize():
     assert got.shape == (6, 3, 224, 224) and torch.equal(got.cpu(), want)
     plain = D.DevicePerturber(DEV).eval_transform(torch.from_numpy(x).to(DEV))
     assert torch.equal(plain.cpu(), I.to_tensor_normalize(torch.from_numpy(r)))
+
+
+def test_device_jpeg_round_trip_equals_pillows_codec():
+    """The device JPEG stage against Pillow's codec itself (the host hook runs PIL on the same frames), qualities 1 ... 100, at the
+    evaluation size and at sides that are not multiples of 8: identical bytes, no bitstream on the device side."""
+    from ssl4polyp_amd.data import DevicePerturber
+    for (H, W) in ((224, 224), (37, 53), (9, 16)):
+        x = torch.from_numpy(_frames(12, H, W, 31, smooth=(H == 224))).to(DEV)
+        rows = [{"variant": f"jpeg_{q}"} for q in (1, 5, 10, 25, 42, 50, 60, 75, 85, 90, 95, 100)]
+        dev = DevicePerturber(DEV)(x, rows)
+        host = DevicePerturber(DEV, jpeg_fn=_pil_jpeg)(x, rows)
+        assert torch.equal(dev, host), (H, W)

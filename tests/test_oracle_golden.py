@@ -206,7 +206,7 @@ def test_bf16_operand_rounding_alone_explains_the_bf16_tolerance(golden):
 def _perturb_cases(golden):
     fx = golden("perturb.npz")
     rows = json.loads(str(fx["rows"]))
-    for name in ("smooth", "noise"):
+    for name in ("smooth", "noise", "odd"):
         img = fx[f"img/{name}"]
         for i, row in enumerate(rows):
             if f"out/{name}/{i}" in fx:
@@ -219,9 +219,8 @@ def test_perturbation_plan_and_oracle_vs_reference(golden):
     """Eval-time perturbations (classification/data/transforms.py:143-203): the product's host-side plan (which perturbation, which
     parameters, which HMAC / rng_seed-seeded rectangle) followed by the oracle's pixel arithmetic (Pillow's box-blur GaussianBlur,
     the ImageEnhance blends, the inclusive rectangle) equals what the REFERENCE's PerRowPerturbations returned, bit for bit -- for
-    every row of tests/golden/perturb.npz, the silently ignored spellings included.  JPEG rows go through Pillow's codec here."""
-    import io
-    from PIL import Image
+    every row of tests/golden/perturb.npz, the silently ignored spellings included -- the JPEG rows too: the oracle restates libjpeg's
+    integer pipeline (colour conversion, islow DCT, quality-scaled quantisation and back) and never builds a bitstream."""
     from oracle import augment_ref as R
     from ssl4polyp_amd import data as D
     fx = golden("perturb.npz")
@@ -240,10 +239,8 @@ def test_perturbation_plan_and_oracle_vs_reference(golden):
             got = R.brightness_contrast(img, plan[1], plan[2])
         elif plan[0] == "occ":
             got = R.occlude(img, D.occlusion_rect(plan[1], plan[2], img.shape[1], img.shape[0]))
-        else:
-            buf = io.BytesIO()
-            Image.fromarray(img).save(buf, format="JPEG", quality=plan[1], optimize=False, subsampling=0)
-            got = np.asarray(Image.open(buf).convert("RGB"))
+        else:   # the codec round trip restated without a bitstream (libjpeg's integer pipeline)
+            got = R.jpeg_roundtrip(img, plan[1])
         assert np.array_equal(got, want), (name, i, row, plan)
     assert kinds == {"none", "blur", "bc", "occ", "jpeg"}
     # the box-blur weights the device kernel receives are the oracle's
