@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, trip 20: full GPU suite on the ABI-12 library (device perturbations added) + default bench line
+# round 4, trip 20: full GPU suite on the final library (ABI 13: device perturbations incl. the JPEG round trip) + default bench line
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out

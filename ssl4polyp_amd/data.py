@@ -453,6 +453,15 @@ class DevicePerturber:
             x = self(x, rows)
         return preprocess_u8(x, None, mean, std)
 
+    def batches(self, loader: Iterable, size: int = 224) -> Iterator[Tuple]:
+        """For the evaluation loop: `loader` yields (decoded uint8 frames [B, Hs, Ws, 3] on the host, labels, rows) -- what
+        PackDataset + pack_collate hand over before the transform (classification/data/packs.py:70-80) -- and this yields
+        (f32 [B, 3, size, size] on the device, labels on the device, rows), i.e. what train.evaluate_cls iterates over, with the
+        rows' perturbations rendered on the way (transforms.py:249-256)."""
+        for frames, labels, rows in loader:
+            x = self.eval_transform(torch.as_tensor(frames).to(self.device, non_blocking=True).contiguous(), rows, size=size)
+            yield x, torch.as_tensor(labels).to(self.device, non_blocking=True), rows
+
     def __call__(self, frames: torch.Tensor, rows) -> torch.Tensor:
         """frames uint8 [B, H, W, 3] on the device, rows: one metadata mapping (or None) per frame.  Returns a new uint8 tensor."""
         import numpy as np

@@ -280,6 +280,11 @@ def test_eval_transform_is_resize_perturb_to_tensor_normalize():
     assert got.shape == (6, 3, 224, 224) and torch.equal(got.cpu(), want)
     plain = D.DevicePerturber(DEV).eval_transform(torch.from_numpy(x).to(DEV))
     assert torch.equal(plain.cpu(), I.to_tensor_normalize(torch.from_numpy(r)))
+    # the same through the loader adaptor of the evaluation loop: host batches (frames, labels, rows) in, device batches out
+    labels = torch.arange(6) % 2
+    batches = list(D.DevicePerturber(DEV).batches([(torch.from_numpy(x[:4]), labels[:4], rows[:4]), (x[4:], labels[4:], rows[4:])]))
+    assert len(batches) == 2 and batches[0][0].is_cuda and batches[0][1].is_cuda and batches[1][2] == rows[4:]
+    assert torch.equal(torch.cat([b[0] for b in batches]), got) and torch.equal(torch.cat([b[1] for b in batches]).cpu(), labels)
 
 
 def test_device_jpeg_round_trip_equals_pillows_codec():
