@@ -86,3 +86,29 @@ def test_device_augmenter_is_gpu_only():
     from ssl4polyp_amd.data import DeviceAugmenter
     with pytest.raises(PolypMaeError):
         DeviceAugmenter("cpu")(torch.zeros(1, 224, 224, 3, dtype=torch.uint8))
+
+
+def test_device_perturber_is_gpu_only_and_its_plan_is_pure_host_logic():
+    """No CPU rendering path behind DevicePerturber (a CPU tensor is refused, not quietly handed to Pillow); the per-row plan is
+    plain Python and does not need a device: spot values of the variant grammar (transforms.py:30-75, 149-203)."""
+    from ssl4polyp_amd._lib import PolypMaeError
+    from ssl4polyp_amd import data as D
+    with pytest.raises(PolypMaeError):
+        D.DevicePerturber("cpu")(torch.zeros(1, 8, 8, 3, dtype=torch.uint8), [{"variant": "blur_1"}])
+    plan = D.perturbation_plan
+    assert plan({"variant": "blur_1p5"}) == ("blur", 1.5) and plan({"variant": "blur_s1p5"}) == ("none",)
+    assert plan({"variant": "blur_1", "blur_sigma": "2.25"}) == ("blur", 2.25) and plan({"variant": "blur_1", "blur_sigma": -1}) == ("blur", 1.0)
+    assert plan({"variant": "jpeg_29p6"}) == ("jpeg", 30) and plan({"variant": "jpeg_90", "jpeg_q": 41.6}) == ("jpeg", 42)
+    assert plan({"variant": "jpeg_q30"}) == ("none",) and plan({"variant": "jpeg_0"}) == ("jpeg", 1) and plan({"variant": "jpeg_250"}) == ("jpeg", 100)
+    assert plan({"variant": "bc_b1p2_c0p8"}) == ("bc", 1.2, 0.8) and plan({"variant": "bc_c1p5"}) == ("bc", None, 1.5)
+    assert plan({"variant": "bc_bminus1", "contrast": 0.5}) == ("bc", -1.0, 0.5)
+    assert plan({"variant": "clean"}) == ("none",) and plan({}) == ("none",) and plan(None) == ("none",)
+    assert plan({"variant": "", "perturbation_id": "blur_2"}) == ("blur", 2.0)
+    assert plan({"variant": "blur_2", "render_in_pipeline": "no"}) == ("none",) and plan({"variant": "blur_2", "render_in_pipeline": "Yes"}) == ("blur", 2.0)
+    occ = plan({"variant": "occ_a0p15", "rng_seed": "12"})
+    assert occ == ("occ", 0.15, 12) and plan({"variant": "occ_aneg1"}) == ("none",)
+    assert D.occlusion_rect(0.0, 1, 224, 224) is None
+    fx0, fy0, fx1, fy1 = D.occlusion_rect(1.0, 1, 224, 224)   # area 1 at an aspect != 1: each side is clipped on its own, as there
+    assert (fx1 - fx0 == 224 or fy1 - fy0 == 224) and 0 <= fx0 <= fx1 <= 224 and 0 <= fy0 <= fy1 <= 224
+    x0, y0, x1, y1 = D.occlusion_rect(0.15, 12, 224, 224)
+    assert 0 <= x0 < x1 <= 224 and 0 <= y0 < y1 <= 224 and 0.10 < (x1 - x0) * (y1 - y0) / 224 ** 2 < 0.20
