@@ -36,7 +36,7 @@ enum pm_dtype { PM_F32 = 0, PM_BF16 = 1, PM_F16 = 2 };
 /* epilogue selector of pm_gemm (what happens to acc = op(A)*op(B) before it is stored) */
 enum pm_epilogue {
   PM_EPI_STORE = 0,      /* C = acc (+bias)                                          (any Linear) */
-  PM_EPI_GELU = 1,       /* aux = acc+bias (pre-activation), C = gelu_erf(acc+bias)  (timm Mlp.fc1 + act) */
+  PM_EPI_GELU = 1,       /* aux = acc+bias (pre-activation; aux NULL: not stored), C = gelu_erf(acc+bias)  (timm Mlp.fc1 + act) */
   PM_EPI_RESIDUAL = 2,   /* C_f32 = resid_f32 + acc + bias                           (Block residual adds) */
   PM_EPI_DGELU = 3,      /* C = acc * gelu_erf'(aux)                                 (backward of Mlp.act) */
   PM_EPI_ACCUM = 4       /* C_f32 += acc                                             (grad accumulation) */
@@ -320,7 +320,9 @@ int pm_aug_jpeg_roundtrip_u8(const unsigned char* src, unsigned char* dst, const
  * would issue itself -- for hosts where ~27 separate calls per block cost more than the block takes to run.  Every
  * pointer addresses row 0 of the range (rows = samples * N tokens); buffers are the saved-for-backward activations:
  * ln1 / qkv [rows, 3D] / attn / ln2 / h_pre / h_act [rows, Hd] act-typed, x / x_mid / x_out f32 [rows, D], mean / rstd f32
- * [rows], lse f32 [samples * heads * N].  The descriptor is plain data: build it once, keep it, pass it every step. */
+ * [rows], lse f32 [samples * heads * N].  h_pre may be NULL when no backward will run through the block (evaluation, a frozen block
+ * under a frozen front): fc1's GELU epilogue then stores the activation only.  The descriptor is plain data: build it once, keep it,
+ * pass it every step. */
 typedef struct pm_block_fwd_desc {
   const float* x;
   float* x_mid;

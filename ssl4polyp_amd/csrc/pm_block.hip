@@ -8,7 +8,7 @@
 
 extern "C" int pm_vit_block_fwd(const pm_block_fwd_desc* d, void* stream) {
   if (!d) return PM_EINVAL;
-  if (!d->x || !d->x_mid || !d->x_out || !d->ln1 || !d->qkv || !d->attn || !d->ln2 || !d->h_pre || !d->h_act) return PM_EINVAL;
+  if (!d->x || !d->x_mid || !d->x_out || !d->ln1 || !d->qkv || !d->attn || !d->ln2 || !d->h_act) return PM_EINVAL;   // (h_pre may be NULL: forward-only)
   if (d->rows <= 0 || d->samples <= 0 || d->N <= 0 || d->rows != d->samples * d->N) return PM_ESHAPE;
   if (d->D <= 0 || d->Hd <= 0 || d->heads <= 0 || (d->D % d->heads)) return PM_ESHAPE;
   if (d->dtype != PM_BF16 && d->dtype != PM_F16 && d->dtype != PM_F32) return PM_EINVAL;

@@ -247,7 +247,7 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int epi, long off, 
     *reinterpret_cast<f32x4*>(c) = *reinterpret_cast<const f32x4*>(c) + v;
   } else {
     if (epi == PM_EPI_GELU) {
-      store4<T>(reinterpret_cast<T*>(a.aux) + off, v);
+      if (a.aux) store4<T>(reinterpret_cast<T*>(a.aux) + off, v);   // (no aux: nobody will run a backward through this Linear)
       v = gelu_act4<T>(round_through<T>(v));  // gelu of the value backward will see
     } else if (epi == PM_EPI_DGELU) {
       const f32x4 pre = load4<T>(reinterpret_cast<const T*>(a.aux) + off);
@@ -290,7 +290,7 @@ __device__ __forceinline__ void epilogue_batch(const GemmArgs& a, int epi, const
   } else if (epi == PM_EPI_GELU) {
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
-      if (ok[e]) store4<E>(reinterpret_cast<E*>(a.aux) + off[e], v[e]);
+      if (a.aux && ok[e]) store4<E>(reinterpret_cast<E*>(a.aux) + off[e], v[e]);
       v[e] = gelu_act4<E>(round_through<E>(v[e]));  // what backward will see
     }
   }
@@ -321,7 +321,7 @@ __device__ __forceinline__ void epilogue_batch8(const GemmArgs& a, int epi, cons
   } else if (epi == PM_EPI_GELU) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      if (ok[u]) store8_16<E>(reinterpret_cast<E*>(a.aux) + off[u], lo[u], hi[u]);
+      if (a.aux && ok[u]) store8_16<E>(reinterpret_cast<E*>(a.aux) + off[u], lo[u], hi[u]);
       lo[u] = gelu_act4<E>(round_through<E>(lo[u]));  // gelu of the value backward will see (the rounded pre-activation)
       hi[u] = gelu_act4<E>(round_through<E>(hi[u]));
     }
@@ -1617,7 +1617,7 @@ int gemm_dispatch(const void* A, long lda, int a_kmajor, const void* B, long ldb
   if ((N & 3) || (ldc & 3)) return PM_EALIGN;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return PM_EALIGN;
   if (epilogue < PM_EPI_STORE || epilogue > PM_EPI_ACCUM) return PM_EINVAL;
-  if ((epilogue == PM_EPI_GELU || epilogue == PM_EPI_DGELU) && !aux) return PM_EINVAL;
+  if (epilogue == PM_EPI_DGELU && !aux) return PM_EINVAL;   // (GELU without aux: the pre-activation is not kept -- forward-only use)
   if (epilogue == PM_EPI_RESIDUAL && (!resid || c_dtype != PM_F32)) return PM_EINVAL;
   if (epilogue == PM_EPI_ACCUM && c_dtype != PM_F32) return PM_EINVAL;
   GemmArgs a;

@@ -408,10 +408,15 @@ class BlockStack:
         self.k, self.g = k, g
 
     def forward(self, ws: StackWorkspace, x_in: torch.Tensor, W: Sequence[Dict[str, torch.Tensor]],
-                before_block: Optional[Callable[[int], None]] = None) -> torch.Tensor:
+                before_block: Optional[Callable[[int], None]] = None, keep_from: int = 0) -> torch.Tensor:
         """x_in f32 [M, D]; W[i] maps BLOCK_PARAM_NAMES -> tensors (matrices act-typed, vectors f32).
-        before_block(i) runs before block i's first kernel (gate on a pending optimizer update of its weights)."""
+        before_block(i) runs before block i's first kernel (gate on a pending optimizer update of its weights).
+        keep_from: no backward will run through blocks below this index (frozen blocks under a frozen front: finetune.py:49-91), so
+        fc1's GELU epilogue does not store their pre-activations (38.7 MB per launch at ViT-B, bs = 64); a forward-only workspace
+        (evaluation, linear probe) keeps none."""
         k, g = self.k, self.g
+        if not ws.training:
+            keep_from = g.depth
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
         # The forward has no second stream of its own work to share the CUs with, so the batch is cut into two halves
         # that run as independent chains on two streams: one half's GEMM tails / attention / LayerNorm fill the CUs
@@ -448,10 +453,11 @@ class BlockStack:
                 # one C call per (block, sample range): pm_vit_block_fwd issues the same seven launches from a descriptor that
                 # is built once and kept (every buffer it names is persistent: workspace, flat parameters, bf16 shadow)
                 for j, (st, b0, b1) in enumerate(parts):
-                    key = (b0, b1, x.data_ptr(), p["attn.qkv.weight"].data_ptr(), p["norm1.weight"].data_ptr(), k.gemm_variant)
+                    key = (b0, b1, x.data_ptr(), p["attn.qkv.weight"].data_ptr(), p["norm1.weight"].data_ptr(), k.gemm_variant,
+                           i >= keep_from)
                     ent = cache.get((i, j))
                     if ent is None or ent[0] != key:
-                        ent = cache[(i, j)] = (key, self._fwd_desc(ws, bw, p, x, b0, b1))
+                        ent = cache[(i, j)] = (key, self._fwd_desc(ws, bw, p, x, b0, b1, keep=i >= keep_from))
                     _lib.check(lib.pm_vit_block_fwd(ctypes.byref(ent[1]), raw[j] if raw[j] is not None else _stream()),
                                "pm_vit_block_fwd")
                 x = bw.x_out
@@ -471,7 +477,7 @@ class BlockStack:
                     k.layernorm_fwd(bw.x_mid[r0:r1], p["norm2.weight"], p["norm2.bias"], bw.ln2[r0:r1], bw.mean2[r0:r1],
                                     bw.rstd2[r0:r1], Mh, D)
                     k.linear_fwd(bw.ln2[r0:r1], p["mlp.fc1.weight"], p["mlp.fc1.bias"], bw.h_act[r0:r1], Mh, Hd, D, EPI_GELU,
-                                 aux=bw.h_pre[r0:r1])
+                                 aux=bw.h_pre[r0:r1] if i >= keep_from else None)
                     k.linear_fwd(bw.h_act[r0:r1], p["mlp.fc2.weight"], p["mlp.fc2.bias"], bw.x_out[r0:r1], Mh, D, Hd,
                                  EPI_RESIDUAL, resid=bw.x_mid[r0:r1])
             x = bw.x_out
@@ -482,8 +488,9 @@ class BlockStack:
                 main.wait_event(ev)
         return x
 
-    def _fwd_desc(self, ws: StackWorkspace, bw: BlockWorkspace, p, x: torch.Tensor, b0: int, b1: int):
-        """pm_block_fwd_desc of block `bw` for samples [b0, b1): every pointer at the first row of the range."""
+    def _fwd_desc(self, ws: StackWorkspace, bw: BlockWorkspace, p, x: torch.Tensor, b0: int, b1: int, keep: bool = True):
+        """pm_block_fwd_desc of block `bw` for samples [b0, b1): every pointer at the first row of the range.  keep = False:
+        h_pre = NULL (the pre-activation of fc1 is not stored: no backward through this block)."""
         k, g = self.k, self.g
         N, D, Hd = ws.N, g.dim, g.hidden
         r0, h0 = b0 * N, b0 * g.heads * N
@@ -492,7 +499,7 @@ class BlockStack:
         return _lib.BlockFwdDesc(
             a(x, r0, D), a(bw.x_mid, r0, D), a(bw.x_out, r0, D), a(bw.ln1, r0, D), a(bw.mean1, r0, 1), a(bw.rstd1, r0, 1),
             a(bw.qkv, r0, 3 * D), a(bw.lse, h0, 1), a(bw.attn, r0, D), a(bw.ln2, r0, D), a(bw.mean2, r0, 1), a(bw.rstd2, r0, 1),
-            a(bw.h_pre, r0, Hd), a(bw.h_act, r0, Hd),
+            a(bw.h_pre, r0, Hd) if keep else None, a(bw.h_act, r0, Hd),
             v(p["norm1.weight"]), v(p["norm1.bias"]), v(p["norm2.weight"]), v(p["norm2.bias"]),
             v(p["attn.qkv.weight"]), v(p["attn.proj.weight"]), v(p["mlp.fc1.weight"]), v(p["mlp.fc2.weight"]),
             v(p["attn.qkv.bias"]), v(p["attn.proj.bias"]), v(p["mlp.fc1.bias"]), v(p["mlp.fc2.bias"]),

@@ -280,7 +280,13 @@ class _VitClsFn(torch.autograd.Function):
         cols, x0 = _EncoderFrontMixin.front_fwd(rt, imgs, None, L)
         ws = rt.get_ws(g, B, N, below)
         W, _ = rt.stack_weights("blocks.", g.depth)
-        x = BlockStack(k, g).forward(ws, x0, W, before_block=_update_gate(rt, "blocks."))
+        # staged fine-tuning (finetune.py:49-91: head + the last one or two blocks): with the front frozen too, no backward reaches
+        # the blocks below the lowest trainable one -- their fc1 pre-activations need not be stored
+        need_map = dict(zip(names, needs))
+        front_needs = any(need_map.get(n, False) for n in ("cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"))
+        keep_from = 0 if front_needs else min((i for i in range(g.depth)
+                                                if any(need_map.get(f"blocks.{i}.{n}", False) for n in BLOCK_PARAM_NAMES)), default=g.depth)
+        x = BlockStack(k, g).forward(ws, x0, W, before_block=_update_gate(rt, "blocks."), keep_from=keep_from)
         rt.wait_updates()  # norm / lin_head and anything else still pending
         dev = imgs.device
         f32 = torch.float32

@@ -146,6 +146,23 @@ def test_gemm_epilogues(prec):
 
 
 @pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("M,N,K", [(394, 3072, 768), (100, 512, 256), (2000, 3072, 768)])
+def test_gelu_epilogue_without_the_pre_activation_store(M, N, K, prec):
+    """PM_EPI_GELU with aux = NULL (forward-only use: evaluation, frozen blocks): the activation equals the one of the storing call
+    bit for bit, through the 128 x 128 kernel and the ring kernels alike, and nothing is written anywhere else."""
+    from ssl4polyp_amd._lib import EPI_GELU
+    k = _k(prec)
+    dt = k.act_dtype
+    x, W, b = rnd(M, K, seed=21).to(dt), rnd(N, K, seed=22, scale=0.05).to(dt), rnd(N, seed=23)
+    out1, aux = torch.empty(M, N, dtype=dt, device=DEV), torch.empty(M, N, dtype=dt, device=DEV)
+    k.linear_fwd(x, W, b, out1, M, N, K, EPI_GELU, aux=aux)
+    out2 = torch.full((M + 1, N), 7.0, dtype=dt, device=DEV)   # (a guard row behind the output)
+    k.linear_fwd(x, W, b, out2, M, N, K, EPI_GELU, aux=None)
+    assert torch.equal(out2[:M], out1) and bool((out2[M] == 7.0).all())
+    assert rel(out1.float(), F.gelu(aux.float())) < ptol(prec, 6e-3, 2e-6)
+
+
+@pytest.mark.parametrize("prec", PRECS)
 def test_linear_helpers_match_autograd(prec):
     """linear_fwd / linear_dgrad / linear_wgrad == nn.Linear forward + backward."""
     k = _k(prec)
