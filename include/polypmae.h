@@ -222,6 +222,13 @@ int pm_mae_loss_bwd(const float* imgs, const float* pred, long ldp, int has_cls_
                     const float* sums, const float* dloss, void* dpred, long lddp, int act_dtype, int B, int C, int img,
                     int p, int norm_pix, void* stream);
 
+/* Rows of a [*, row_bytes] array by index, and back into an all-zero array (engine: the classifier's top block under out_token
+ * "cls" -- models.py:134-136 -- whose incoming gradient lives in one row per sample):
+ *   pm_gather_rows      : dst[r] = src[idx[r]] for r < R          (row_bytes % 4 == 0; source row pitch ld_bytes)
+ *   pm_scatter_rows_zero: dst[m] = inv[m] >= 0 ? src[inv[m]] : 0  for m < M   (row_bytes % 16 == 0, 16-byte aligned buffers) */
+int pm_gather_rows(const void* src, long ld_bytes, const int* idx, void* dst, int R, long row_bytes, void* stream);
+int pm_scatter_rows_zero(const void* src, const int* inv, void* dst, int M, long row_bytes, void* stream);
+
 /* f32 -> act cast (weight shadow copies for the bf16 MFMA path). */
 int pm_cast(const float* src, void* dst, int dst_dtype, long n, void* stream);
 

@@ -46,6 +46,8 @@ SIGNATURES = {
     "pm_mae_loss_finish": [P, P, L, P, P, P],
     "pm_mae_loss_bwd": [P, P, L, I, P, P, P, P, L, I, I, I, I, I, I, P],
     "pm_cast": [P, P, I, L, P],
+    "pm_gather_rows": [P, L, P, P, I, L, P],
+    "pm_scatter_rows_zero": [P, P, P, I, L, P],
     "pm_preprocess_u8": [P, P, P, I, I, I, F, F, F, F, F, F, P],
     "pm_aug_resize_u8": [P, P, P, P, P, I, P, P, I, I, I, I, I, I, P],
     "pm_aug_resized_crop_u8": [P, P, P, I, I, I, I, I, P, ctypes.c_size_t, P],
@@ -74,7 +76,7 @@ SIGNATURES = {
     "pm_dgelu": [P, P, P, I, L, P],
 }
 
-ABI_VERSION = 13  # pm_abi_version() of the library these signatures describe
+ABI_VERSION = 14  # pm_abi_version() of the library these signatures describe
 PM_GROUP_WHOLE_K = -1  # pm_wgrad_group(max_blocks=...): never slice, whole-K 256x256 tiles
 
 WS_LAYERNORM_BWD, WS_COLSUM, WS_GEMM_COLSUM, WS_UNSHUFFLE_BWD = 1, 2, 3, 4

@@ -400,6 +400,34 @@ inline int cap_grid(long work_items, int per_block, int cap) {
   return (int)g;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Row gather / scatter for the classifier's top block (engine.py BlockStack.backward, sparse_top): with out_token "cls" the head's
+// backward leaves a gradient in ONE row per sample, and the MLP branch of the last block (dfc2 + dGELU, dfc1, LayerNorm backward,
+// proj dgrad and three of the four weight gradients) sees nothing but those rows until the attention backward spreads them again.
+// ---------------------------------------------------------------------------------------------
+// dst[r][:] = src[idx[r]][:], rows of `words` 32-bit words (source row pitch ld_words)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const unsigned int* __restrict__ src, long ld_words, const int* __restrict__ idx,
+                                                          unsigned int* __restrict__ dst, int R, long words) {
+  const long total = (long)R * words;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = i / words;
+    const long w = i % words;
+    dst[i] = src[(long)idx[r] * ld_words + w];
+  }
+}
+// dst[m][:] = inv[m] >= 0 ? src[inv[m]][:] : 0 for all M rows of `vecs` 16-byte vectors
+__global__ __launch_bounds__(256) void scatter_rows_zero_kernel(const u32x4* __restrict__ src, const int* __restrict__ inv,
+                                                                u32x4* __restrict__ dst, int M, long vecs) {
+  const long total = (long)M * vecs;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = i / vecs;
+    const long v = i % vecs;
+    const int r = inv[m];
+    dst[i] = r >= 0 ? src[(long)r * vecs + v] : u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
 }  // namespace
 
 extern "C" int pm_colsum_ws(const void* x, long ldx, int dtype, float* out, int M, int N, void* workspace, size_t ws_bytes,
@@ -498,6 +526,26 @@ extern "C" int pm_cast(const float* src, void* dst, int dst_dtype, long n, void*
   return pm_check_launch();
 }
 
+extern "C" int pm_gather_rows(const void* src, long ld_bytes, const int* idx, void* dst, int R, long row_bytes, void* stream) {
+  if (!src || !idx || !dst) return PM_EINVAL;
+  if (R <= 0 || row_bytes <= 0 || ld_bytes < row_bytes) return PM_ESHAPE;
+  if ((row_bytes & 3) || (ld_bytes & 3) || ((uintptr_t)src & 3) || ((uintptr_t)dst & 3)) return PM_EALIGN;
+  const long total = (long)R * (row_bytes >> 2);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cap_grid(total, 256, 4096)), dim3(256), 0, pm_stream(stream), (const unsigned int*)src,
+                     ld_bytes >> 2, idx, (unsigned int*)dst, R, row_bytes >> 2);
+  return pm_check_launch();
+}
+
+extern "C" int pm_scatter_rows_zero(const void* src, const int* inv, void* dst, int M, long row_bytes, void* stream) {
+  if (!src || !inv || !dst) return PM_EINVAL;
+  if (M <= 0 || row_bytes <= 0) return PM_ESHAPE;
+  if ((row_bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return PM_EALIGN;
+  const long total = (long)M * (row_bytes >> 4);
+  hipLaunchKernelGGL(scatter_rows_zero_kernel, dim3(cap_grid(total, 256, 8192)), dim3(256), 0, pm_stream(stream), (const u32x4*)src, inv,
+                     (u32x4*)dst, M, row_bytes >> 4);
+  return pm_check_launch();
+}
+
 extern "C" int pm_dgelu(const void* dy, const void* pre, void* out, int dtype, long n, void* stream) {
   if (!dy || !pre || !out) return PM_EINVAL;
   if (n <= 0 || (n & 3)) return PM_ESHAPE;
@@ -573,7 +621,7 @@ extern "C" const char* pm_strerror(int status) {
 
 // 3: pm_gemm_ex / pm_gemm_opts replace pm_tune, workspace queries, pm_vit_head_*, pm_supervised_loss_fwd, pm_scale
 // 10: PM_F16 (precision mode fp16), pm_loss_scale_update, pm_dgelu
-extern "C" int pm_abi_version(void) { return 13; }
+extern "C" int pm_abi_version(void) { return 14; }
 
 extern "C" size_t pm_workspace_bytes(int kind, int M, int N) {
   if (M <= 0 || N <= 0) return 0;

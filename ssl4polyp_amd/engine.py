@@ -316,6 +316,21 @@ class Kernels:
         _lib.check(self.lib.pm_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(delta), _ptr(dqkv), B, N,
                                              H, dh, self.act, _stream()), "pm_attention_bwd")
 
+    def gather_rows(self, src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """dst[r] = src[idx[r]] for a 2-D (or 1-D) contiguous src; idx int32 on the device."""
+        rows = src if src.ndim == 2 else src.view(-1, 1)
+        dst = torch.empty(idx.numel(), rows.shape[1], dtype=src.dtype, device=src.device)
+        rb = rows.shape[1] * src.element_size()
+        _lib.check(self.lib.pm_gather_rows(_ptr(rows), rb, _ptr(idx), _ptr(dst), idx.numel(), rb, _stream()), "pm_gather_rows")
+        return dst if src.ndim == 2 else dst.view(-1)
+
+    def scatter_rows_zero(self, src: torch.Tensor, inv: torch.Tensor, dst: torch.Tensor) -> None:
+        """dst[m] = src[inv[m]] where inv[m] >= 0, zeros elsewhere (every row of dst is written)."""
+        _lib.check(self.lib.pm_scatter_rows_zero(_ptr(src), _ptr(inv), _ptr(dst), dst.shape[0], dst.shape[1] * dst.element_size(),
+                                                 _stream()), "pm_scatter_rows_zero")
+
+    SPARSE_TOP = os.environ.get("PM_SPARSE_TOP", "1") != "0"   # A/B switch: the classifier's top block on its cls rows (backward)
+
     def cast(self, src, dst):
         _lib.check(self.lib.pm_cast(_ptr(src), _ptr(dst), _lib.dtype_code(dst.dtype), src.numel(), _stream()), "pm_cast")
 
@@ -545,7 +560,8 @@ class BlockStack:
                  last_bias_grad_done: bool, trainable: Sequence[bool], need_input_grad: bool,
                  accumulate: Callable[[str, int], bool], on_block_done: Optional[Callable[[int], None]] = None,
                  prev_bias_grad: Optional[torch.Tensor] = None,
-                 ends_pass: bool = True, defer_join: bool = False) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+                 ends_pass: bool = True, defer_join: bool = False,
+                 sparse_top: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
         """dx / dx_act: gradient w.r.t. the stack output (f32 + act copy).  G[i][name] = f32 gradient
         tensors (vectors are += targets and must be zeroed or hold the running sum; matrices follow
         accumulate(name, i)).  `last_bias_grad_done`: the producer of dx already added colsum(dx) into the
@@ -555,6 +571,9 @@ class BlockStack:
         `defer_join`: do not make the main stream wait for the last blocks' weight gradients here -- the caller still has
         main-stream work that does not read them (the embedding's backward) and calls `join_deferred(ws)` after it; the side
         stream's last launches then run beside that work instead of in front of it.
+        `sparse_top` = (rows, inv): the incoming dx is zero outside the rows `rows` (int32 indices; inv[m] = position of row m in
+        `rows` or -1) -- the classifier head under out_token "cls" (models.py:134-136) leaves one row per sample.  The MLP branch of
+        the top block and its proj Linear then run on those rows only (see _top_block_sparse).
         Returns (dx_in f32, dx_in act) or (None, None) when nothing below needs it."""
         k, g = self.k, self.g
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
@@ -588,6 +607,13 @@ class BlockStack:
             pin = next((j for j in range(5) if dx_act is ws.dx_act[j]), 4)
             dmid_act, din_act = ws.dx_act[(pin + 1) % 5], ws.dx_act[(pin + 2) % 5]
             join(i + 2)  # block i overwrites what the side stream read for block i+2
+            if (i == g.depth - 1 and sparse_top is not None and tr and (need_input_grad or i > lowest or tr) and
+                    sparse_top[0].numel() % 8 == 0 and sparse_top[0].numel() < M):
+                below_bias = (G[i - 1]["mlp.fc2.bias"] if trainable[i - 1] else None) if i > 0 else prev_bias_grad
+                pending[i] = self._top_block_sparse(ws, bw, p, gr, xin, dx, dx_act, sparse_top, last_bias_grad_done, dmid, din, din_act,
+                                                    d_qkv, below_bias, lambda n: accumulate(n, i), main, on_block_done, i)
+                dx, dx_act = din, din_act
+                continue
             if i == g.depth - 1 and not last_bias_grad_done and tr:
                 k.colsum(dx, gr["mlp.fc2.bias"], M, D)
             # Weight gradients run on a side stream, concurrently with the dgrad chain on the main stream: the two
@@ -719,6 +745,61 @@ class BlockStack:
         else:
             join(0)
         return dx, dx_act
+
+    def _top_block_sparse(self, ws, bw, p, gr, xin, dx, dx_act, sparse_top, last_bias_grad_done, dmid, din, din_act, d_qkv, below_bias,
+                          acc, main, on_block_done, i):
+        """Backward of a TRAINABLE top block whose incoming gradient is zero outside `rows` (B of the B * N token rows).  Zero rows of dY
+        contribute nothing to a dgrad row, to a weight gradient or to LayerNorm's column sums, and the residual path adds zero to zero:
+        until the attention backward spreads the gradient over all keys again, every kernel of the dense chain multiplies zeros --
+        dfc2 + dGELU, dfc1, LayerNorm2', proj dgrad and the fc2 / fc1 / proj weight gradients (at ViT-B, bs = 64: 12 608 rows, 64 of
+        them live).  Here those run on the gathered rows (M = B), the results are scattered into zero-filled dense buffers for the
+        attention backward, and the rest of the block (qkv weight gradient on the side stream, qkv dgrad, LayerNorm1') is dense as ever.
+        Same per-row arithmetic as the dense chain; the weight gradients sum the same non-zero products in a different order."""
+        k, g = self.k, self.g
+        rows, inv = sparse_top
+        B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
+        R = rows.numel()
+        dev, f32 = dx.device, torch.float32
+        e = lambda *s, dt=k.act_dtype: torch.empty(*s, dtype=dt, device=dev)
+        dxc, dxac = k.gather_rows(dx.view(M, D), rows), k.gather_rows(dx_act.view(M, D), rows)
+        hpre_c, hact_c = k.gather_rows(bw.h_pre.view(M, Hd), rows), k.gather_rows(bw.h_act.view(M, Hd), rows)
+        ln2_c, xmid_c, attn_c = k.gather_rows(bw.ln2.view(M, D), rows), k.gather_rows(bw.x_mid.view(M, D), rows), k.gather_rows(bw.attn.view(M, D), rows)
+        mean2_c, rstd2_c = k.gather_rows(bw.mean2, rows), k.gather_rows(bw.rstd2, rows)
+        if not last_bias_grad_done:
+            k.colsum(dxc, gr["mlp.fc2.bias"], R, D)
+        # ---- MLP branch on the live rows
+        d_hidden_c = e(R, Hd)
+        k.linear_dgrad(dxac, p["mlp.fc2.weight"], d_hidden_c, R, D, Hd, EPI_DGELU, aux=hpre_c)
+        k.linear_wgrad(dxac, hact_c, gr["mlp.fc2.weight"], R, D, Hd, acc("mlp.fc2.weight"), ws_name="_ws_front")
+        k.linear_wgrad(d_hidden_c, ln2_c, gr["mlp.fc1.weight"], R, Hd, D, acc("mlp.fc1.weight"), ws_name="_ws_front")
+        k.colsum(d_hidden_c, gr["mlp.fc1.bias"], R, Hd)
+        d_ln_c = e(R, D)
+        k.linear_dgrad(d_hidden_c, p["mlp.fc1.weight"], d_ln_c, R, Hd, D)
+        dmid_c, dmid_act_c = e(R, D, dt=f32), e(R, D)
+        k.layernorm_bwd(d_ln_c, xmid_c, p["norm2.weight"], mean2_c, rstd2_c, dxc, dmid_c, dmid_act_c, gr["norm2.weight"], gr["norm2.bias"],
+                        gr["attn.proj.bias"], R, D)
+        # ---- proj on the live rows, then dense again for the attention backward
+        k.linear_wgrad(dmid_act_c, attn_c, gr["attn.proj.weight"], R, D, D, acc("attn.proj.weight"), ws_name="_ws_front")
+        d_attn_c = e(R, D)
+        k.linear_dgrad(dmid_act_c, p["attn.proj.weight"], d_attn_c, R, D, D)
+        k.scatter_rows_zero(dmid_c, inv, dmid.view(M, D))
+        k.scatter_rows_zero(d_attn_c, inv, ws.d_attn.view(M, D))
+        k.attention_bwd(bw.qkv, bw.attn, ws.d_attn, bw.lse, ws.delta, d_qkv, B, N, g.heads, g.dh)
+        side = k.side_stream(main.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            k.colsum(d_qkv, gr["attn.qkv.bias"], M, 3 * D)
+            k.linear_wgrad(d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, acc("attn.qkv.weight"))
+            ev_last = torch.cuda.Event()
+            ev_last.record(side)
+            if on_block_done is not None:
+                on_block_done(i)
+        k.linear_dgrad(d_qkv, p["attn.qkv.weight"], ws.d_ln, M, 3 * D, D)
+        k.layernorm_bwd(ws.d_ln, xin, p["norm1.weight"], bw.mean1, bw.rstd1, dmid, din, din_act, gr["norm1.weight"], gr["norm1.bias"],
+                        below_bias, M, D)
+        return (ev_last,)
 
     @staticmethod
     def join_deferred(ws: StackWorkspace) -> None:

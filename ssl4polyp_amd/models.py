@@ -127,6 +127,17 @@ class _Runtime:
                 st.wait_event(ev)
             del self.pending_updates[:last + 1]
 
+    def cls_rows(self, B: int, N: int, dev):
+        """(rows, inv) of BlockStack.backward(sparse_top=...): the cls-token row of every sample among the B * N token rows."""
+        key = ("cls_rows", B, N)
+        hit = self._wcache.get(key)
+        if hit is None:
+            rows = (torch.arange(B, dtype=torch.int32) * N)
+            inv = torch.full((B * N,), -1, dtype=torch.int32)
+            inv[rows.long()] = torch.arange(B, dtype=torch.int32)
+            hit = self._wcache[key] = (rows.to(dev), inv.to(dev))
+        return hit
+
     def block_end(self, prefix: str, i: int) -> int:
         """End offset (in `mat`) of block i's matrices: what `wait_updates` needs before the block runs."""
         f = self.flat
@@ -353,8 +364,12 @@ class _VitClsFn(torch.autograd.Function):
             # the incoming dx lives in ws.dx[0]; an odd-depth stack would start writing ws.dx[1] first: fine either way
             # the embedding's backward does not read the blocks' weight gradients: it runs BEFORE the main stream joins the
             # side stream, beside the tail block's last weight-gradient launches instead of behind them
+            # out_token "cls" (models.py:134-136): the head's backward left a gradient in row 0 of every sample and zeros elsewhere
+            sparse = None
+            if pool == 0 and k.SPARSE_TOP and trainable[g.depth - 1]:
+                sparse = rt.cls_rows(B, N, dev=dout.device)
             dx0, _ = BlockStack(k, g).backward(ws, x0, W, G, dx, dx_act, False, trainable, front,
-                                               lambda n, i: accumulate, cb, defer_join=k.DEFER_JOIN)
+                                               lambda n, i: accumulate, cb, defer_join=k.DEFER_JOIN, sparse_top=sparse)
             if front and dx0 is not None:
                 _EncoderFrontMixin.front_bwd(rt, dx0, cols, None, B, L, accumulate, need, learn_pos)
             BlockStack.join_deferred(ws)
