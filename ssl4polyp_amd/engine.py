@@ -316,10 +316,10 @@ class Kernels:
         _lib.check(self.lib.pm_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(delta), _ptr(dqkv), B, N,
                                              H, dh, self.act, _stream()), "pm_attention_bwd")
 
-    def gather_rows(self, src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-        """dst[r] = src[idx[r]] for a 2-D (or 1-D) contiguous src; idx int32 on the device."""
+    def gather_rows(self, src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dst[r] = src[idx[r]] for a 2-D (or 1-D) contiguous src; idx int32 on the device; out: a contiguous [R, width] destination."""
         rows = src if src.ndim == 2 else src.view(-1, 1)
-        dst = torch.empty(idx.numel(), rows.shape[1], dtype=src.dtype, device=src.device)
+        dst = out if out is not None else torch.empty(idx.numel(), rows.shape[1], dtype=src.dtype, device=src.device)
         rb = rows.shape[1] * src.element_size()
         _lib.check(self.lib.pm_gather_rows(_ptr(rows), rb, _ptr(idx), _ptr(dst), idx.numel(), rb, _stream()), "pm_gather_rows")
         return dst if src.ndim == 2 else dst.view(-1)
@@ -423,15 +423,19 @@ class BlockStack:
         self.k, self.g = k, g
 
     def forward(self, ws: StackWorkspace, x_in: torch.Tensor, W: Sequence[Dict[str, torch.Tensor]],
-                before_block: Optional[Callable[[int], None]] = None, keep_from: int = 0) -> torch.Tensor:
+                before_block: Optional[Callable[[int], None]] = None, keep_from: int = 0, cls_top: bool = False) -> torch.Tensor:
         """x_in f32 [M, D]; W[i] maps BLOCK_PARAM_NAMES -> tensors (matrices act-typed, vectors f32).
         before_block(i) runs before block i's first kernel (gate on a pending optimizer update of its weights).
         keep_from: no backward will run through blocks below this index (frozen blocks under a frozen front: finetune.py:49-91), so
         fc1's GELU epilogue does not store their pre-activations (38.7 MB per launch at ViT-B, bs = 64); a forward-only workspace
-        (evaluation, linear probe) keeps none."""
+        (evaluation, linear probe) keeps none.
+        cls_top: the caller reads row 0 of every sample of the result only (out_token "cls", models.py:134-136).  Behind its attention,
+        the TOP block is then per-token work whose other rows nobody reads: proj + residual, LayerNorm2, fc1 + GELU, fc2 + residual run
+        on the B cls rows (gathered behind the attention), and the result comes back as [B, D] (= [B, 1, D] for the head kernels)."""
         k, g = self.k, self.g
         if not ws.training:
             keep_from = g.depth
+        cls_top = cls_top and ws.N > 1 and g.depth >= 1
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
         # The forward has no second stream of its own work to share the CUs with, so the batch is cut into two halves
         # that run as independent chains on two streams: one half's GEMM tails / attention / LayerNorm fill the CUs
@@ -464,6 +468,9 @@ class BlockStack:
                 else:
                     before_block(i)
             bw, p = ws.block(i), W[i]
+            if cls_top and i == g.depth - 1:
+                x = self._top_block_forward_cls(ws, bw, p, x, parts, main, i >= keep_from)
+                continue
             if fast:
                 # one C call per (block, sample range): pm_vit_block_fwd issues the same seven launches from a descriptor that
                 # is built once and kept (every buffer it names is persistent: workspace, flat parameters, bf16 shadow)
@@ -502,6 +509,47 @@ class BlockStack:
                 ev.record(aux)
                 main.wait_event(ev)
         return x
+
+    @staticmethod
+    def top_compact(ws: StackWorkspace, g: StackGeom, act_dtype, dev) -> dict:
+        """Compact [B, ...] buffers of the top block's cls rows (forward saves + the head's gradient), kept on the workspace."""
+        tc = ws.__dict__.get("_top_c")
+        if tc is None:
+            B, N, D, Hd, f32 = ws.B, ws.N, g.dim, g.hidden, torch.float32
+            e = lambda *s, dt=act_dtype: torch.empty(*s, dtype=dt, device=dev)
+            rows = (torch.arange(B, dtype=torch.int32) * N).to(dev)
+            inv = torch.full((B * N,), -1, dtype=torch.int32)
+            inv[(torch.arange(B) * N)] = torch.arange(B, dtype=torch.int32)
+            tc = ws.__dict__["_top_c"] = dict(
+                rows=rows, inv=inv.to(dev), x=e(B, D, dt=f32), attn=e(B, D), x_mid=e(B, D, dt=f32), ln2=e(B, D), mean2=e(B, dt=f32),
+                rstd2=e(B, dt=f32), h_pre=e(B, Hd), h_act=e(B, Hd), x_out=e(B, D, dt=f32), dx=e(B, D, dt=f32), dx_act=e(B, D))
+        return tc
+
+    def _top_block_forward_cls(self, ws, bw, p, x, parts, main, keep: bool) -> torch.Tensor:
+        k, g = self.k, self.g
+        N, D, Hd = ws.N, g.dim, g.hidden
+        tc = self.top_compact(ws, g, k.act_dtype, x.device)
+        for st, b0, b1 in parts:
+            r0, r1, Bh = b0 * N, b1 * N, b1 - b0
+            Mh = r1 - r0
+            h0, h1 = b0 * g.heads * N, b1 * g.heads * N
+            with (torch.cuda.stream(st) if st is not None and st is not main else contextlib.nullcontext()):
+                xs = x[r0:r1]
+                k.layernorm_fwd(xs, p["norm1.weight"], p["norm1.bias"], bw.ln1[r0:r1], bw.mean1[r0:r1], bw.rstd1[r0:r1], Mh, D)
+                k.linear_fwd(bw.ln1[r0:r1], p["attn.qkv.weight"], p["attn.qkv.bias"], bw.qkv[r0:r1], Mh, 3 * D, D)
+                k.attention_fwd(bw.qkv[r0:r1], bw.attn[r0:r1], bw.lse[h0:h1], Bh, N, g.heads, g.dh)
+                idx = tc["rows"][b0:b1]
+                k.gather_rows(x.view(-1, D), idx, out=tc["x"][b0:b1])
+                k.gather_rows(bw.attn.view(-1, D), idx, out=tc["attn"][b0:b1])
+                k.linear_fwd(tc["attn"][b0:b1], p["attn.proj.weight"], p["attn.proj.bias"], tc["x_mid"][b0:b1], Bh, D, D, EPI_RESIDUAL,
+                             resid=tc["x"][b0:b1])
+                k.layernorm_fwd(tc["x_mid"][b0:b1], p["norm2.weight"], p["norm2.bias"], tc["ln2"][b0:b1], tc["mean2"][b0:b1],
+                                tc["rstd2"][b0:b1], Bh, D)
+                k.linear_fwd(tc["ln2"][b0:b1], p["mlp.fc1.weight"], p["mlp.fc1.bias"], tc["h_act"][b0:b1], Bh, Hd, D, EPI_GELU,
+                             aux=tc["h_pre"][b0:b1] if keep else None)
+                k.linear_fwd(tc["h_act"][b0:b1], p["mlp.fc2.weight"], p["mlp.fc2.bias"], tc["x_out"][b0:b1], Bh, D, Hd, EPI_RESIDUAL,
+                             resid=tc["x_mid"][b0:b1])
+        return tc["x_out"]
 
     def _fwd_desc(self, ws: StackWorkspace, bw: BlockWorkspace, p, x: torch.Tensor, b0: int, b1: int, keep: bool = True):
         """pm_block_fwd_desc of block `bw` for samples [b0, b1): every pointer at the first row of the range.  keep = False:
@@ -571,9 +619,8 @@ class BlockStack:
         `defer_join`: do not make the main stream wait for the last blocks' weight gradients here -- the caller still has
         main-stream work that does not read them (the embedding's backward) and calls `join_deferred(ws)` after it; the side
         stream's last launches then run beside that work instead of in front of it.
-        `sparse_top` = (rows, inv): the incoming dx is zero outside the rows `rows` (int32 indices; inv[m] = position of row m in
-        `rows` or -1) -- the classifier head under out_token "cls" (models.py:134-136) leaves one row per sample.  The MLP branch of
-        the top block and its proj Linear then run on those rows only (see _top_block_sparse).
+        `sparse_top` (any non-None value): the forward ran with cls_top and dx / dx_act are the head's gradient on the B cls rows
+        ([B, D]); the top block's backward then runs on those rows up to its attention (see _top_block_sparse).
         Returns (dx_in f32, dx_in act) or (None, None) when nothing below needs it."""
         k, g = self.k, self.g
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
@@ -607,11 +654,14 @@ class BlockStack:
             pin = next((j for j in range(5) if dx_act is ws.dx_act[j]), 4)
             dmid_act, din_act = ws.dx_act[(pin + 1) % 5], ws.dx_act[(pin + 2) % 5]
             join(i + 2)  # block i overwrites what the side stream read for block i+2
-            if (i == g.depth - 1 and sparse_top is not None and tr and (need_input_grad or i > lowest or tr) and
-                    sparse_top[0].numel() % 8 == 0 and sparse_top[0].numel() < M):
+            if i == g.depth - 1 and sparse_top is not None:
+                if tr and ws.B % 8:
+                    raise _lib.PolypMaeError("the cls-row top block needs a batch that is a multiple of 8 to train (16-byte k-major rows)")
                 below_bias = (G[i - 1]["mlp.fc2.bias"] if trainable[i - 1] else None) if i > 0 else prev_bias_grad
-                pending[i] = self._top_block_sparse(ws, bw, p, gr, xin, dx, dx_act, sparse_top, last_bias_grad_done, dmid, din, din_act,
-                                                    d_qkv, below_bias, lambda n: accumulate(n, i), main, on_block_done, i)
+                ev_last = self._top_block_sparse(ws, bw, p, gr, xin, dx, dx_act, sparse_top, last_bias_grad_done, dmid, din, din_act,
+                                                 d_qkv, below_bias, lambda n: accumulate(n, i), main, on_block_done, i, tr)
+                if ev_last is not None:
+                    pending[i] = ev_last
                 dx, dx_act = din, din_act
                 continue
             if i == g.depth - 1 and not last_bias_grad_done and tr:
@@ -747,59 +797,64 @@ class BlockStack:
         return dx, dx_act
 
     def _top_block_sparse(self, ws, bw, p, gr, xin, dx, dx_act, sparse_top, last_bias_grad_done, dmid, din, din_act, d_qkv, below_bias,
-                          acc, main, on_block_done, i):
-        """Backward of a TRAINABLE top block whose incoming gradient is zero outside `rows` (B of the B * N token rows).  Zero rows of dY
-        contribute nothing to a dgrad row, to a weight gradient or to LayerNorm's column sums, and the residual path adds zero to zero:
-        until the attention backward spreads the gradient over all keys again, every kernel of the dense chain multiplies zeros --
-        dfc2 + dGELU, dfc1, LayerNorm2', proj dgrad and the fc2 / fc1 / proj weight gradients (at ViT-B, bs = 64: 12 608 rows, 64 of
-        them live).  Here those run on the gathered rows (M = B), the results are scattered into zero-filled dense buffers for the
-        attention backward, and the rest of the block (qkv weight gradient on the side stream, qkv dgrad, LayerNorm1') is dense as ever.
-        Same per-row arithmetic as the dense chain; the weight gradients sum the same non-zero products in a different order."""
+                          acc, main, on_block_done, i, tr):
+        """Backward of the top block of a classifier that reads the cls row only (forward: _top_block_forward_cls).  dx / dx_act are the
+        head's gradient on the B cls rows ([B, D], pm_vit_head_bwd with N = 1); the block's saves behind the attention are compact too.
+        The MLP branch and the proj Linear -- dfc2 + dGELU, dfc1, LayerNorm2', proj dgrad, the fc2 / fc1 / proj weight gradients -- run at
+        M = B; d mid and d attn are scattered into zero-filled dense buffers (a zero row of dY adds nothing anywhere, and the residual
+        path adds zero to zero), and from the attention backward on -- which spreads the gradient over all keys -- the block is dense:
+        qkv weight gradient on the side stream, qkv dgrad, LayerNorm1'.  The reference's autograd multiplies those zeros; skipping them
+        is the same kind of identity as embedding only the kept patches in MAE."""
         k, g = self.k, self.g
-        rows, inv = sparse_top
+        tc = self.top_compact(ws, g, k.act_dtype, dx.device)
+        rows, inv = tc["rows"], tc["inv"]
         B, N, M, D, Hd = ws.B, ws.N, ws.M, g.dim, g.hidden
-        R = rows.numel()
+        R = B
         dev, f32 = dx.device, torch.float32
         e = lambda *s, dt=k.act_dtype: torch.empty(*s, dtype=dt, device=dev)
-        dxc, dxac = k.gather_rows(dx.view(M, D), rows), k.gather_rows(dx_act.view(M, D), rows)
-        hpre_c, hact_c = k.gather_rows(bw.h_pre.view(M, Hd), rows), k.gather_rows(bw.h_act.view(M, Hd), rows)
-        ln2_c, xmid_c, attn_c = k.gather_rows(bw.ln2.view(M, D), rows), k.gather_rows(bw.x_mid.view(M, D), rows), k.gather_rows(bw.attn.view(M, D), rows)
-        mean2_c, rstd2_c = k.gather_rows(bw.mean2, rows), k.gather_rows(bw.rstd2, rows)
-        if not last_bias_grad_done:
+        dxc, dxac = dx.view(R, D), dx_act.view(R, D)
+        G_ = (lambda n: gr[n]) if tr else (lambda n: None)
+        if tr and not last_bias_grad_done:
             k.colsum(dxc, gr["mlp.fc2.bias"], R, D)
         # ---- MLP branch on the live rows
         d_hidden_c = e(R, Hd)
-        k.linear_dgrad(dxac, p["mlp.fc2.weight"], d_hidden_c, R, D, Hd, EPI_DGELU, aux=hpre_c)
-        k.linear_wgrad(dxac, hact_c, gr["mlp.fc2.weight"], R, D, Hd, acc("mlp.fc2.weight"), ws_name="_ws_front")
-        k.linear_wgrad(d_hidden_c, ln2_c, gr["mlp.fc1.weight"], R, Hd, D, acc("mlp.fc1.weight"), ws_name="_ws_front")
-        k.colsum(d_hidden_c, gr["mlp.fc1.bias"], R, Hd)
+        k.linear_dgrad(dxac, p["mlp.fc2.weight"], d_hidden_c, R, D, Hd, EPI_DGELU, aux=tc["h_pre"])
+        if tr:
+            k.linear_wgrad(dxac, tc["h_act"], gr["mlp.fc2.weight"], R, D, Hd, acc("mlp.fc2.weight"), ws_name="_ws_front")
+            k.linear_wgrad(d_hidden_c, tc["ln2"], gr["mlp.fc1.weight"], R, Hd, D, acc("mlp.fc1.weight"), ws_name="_ws_front")
+            k.colsum(d_hidden_c, gr["mlp.fc1.bias"], R, Hd)
         d_ln_c = e(R, D)
         k.linear_dgrad(d_hidden_c, p["mlp.fc1.weight"], d_ln_c, R, Hd, D)
         dmid_c, dmid_act_c = e(R, D, dt=f32), e(R, D)
-        k.layernorm_bwd(d_ln_c, xmid_c, p["norm2.weight"], mean2_c, rstd2_c, dxc, dmid_c, dmid_act_c, gr["norm2.weight"], gr["norm2.bias"],
-                        gr["attn.proj.bias"], R, D)
+        k.layernorm_bwd(d_ln_c, tc["x_mid"], p["norm2.weight"], tc["mean2"], tc["rstd2"], dxc, dmid_c, dmid_act_c, G_("norm2.weight"),
+                        G_("norm2.bias"), G_("attn.proj.bias"), R, D)
         # ---- proj on the live rows, then dense again for the attention backward
-        k.linear_wgrad(dmid_act_c, attn_c, gr["attn.proj.weight"], R, D, D, acc("attn.proj.weight"), ws_name="_ws_front")
+        if tr:
+            k.linear_wgrad(dmid_act_c, tc["attn"], gr["attn.proj.weight"], R, D, D, acc("attn.proj.weight"), ws_name="_ws_front")
         d_attn_c = e(R, D)
         k.linear_dgrad(dmid_act_c, p["attn.proj.weight"], d_attn_c, R, D, D)
         k.scatter_rows_zero(dmid_c, inv, dmid.view(M, D))
         k.scatter_rows_zero(d_attn_c, inv, ws.d_attn.view(M, D))
         k.attention_bwd(bw.qkv, bw.attn, ws.d_attn, bw.lse, ws.delta, d_qkv, B, N, g.heads, g.dh)
-        side = k.side_stream(main.device)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            k.colsum(d_qkv, gr["attn.qkv.bias"], M, 3 * D)
-            k.linear_wgrad(d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, acc("attn.qkv.weight"))
-            ev_last = torch.cuda.Event()
-            ev_last.record(side)
-            if on_block_done is not None:
-                on_block_done(i)
+        ev_last = None
+        if tr:
+            side = k.side_stream(main.device)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                k.colsum(d_qkv, gr["attn.qkv.bias"], M, 3 * D)
+                k.linear_wgrad(d_qkv, bw.ln1, gr["attn.qkv.weight"], M, 3 * D, D, acc("attn.qkv.weight"))
+                ev_last = torch.cuda.Event()
+                ev_last.record(side)
+                if on_block_done is not None:
+                    on_block_done(i)
         k.linear_dgrad(d_qkv, p["attn.qkv.weight"], ws.d_ln, M, 3 * D, D)
-        k.layernorm_bwd(ws.d_ln, xin, p["norm1.weight"], bw.mean1, bw.rstd1, dmid, din, din_act, gr["norm1.weight"], gr["norm1.bias"],
+        k.layernorm_bwd(ws.d_ln, xin, p["norm1.weight"], bw.mean1, bw.rstd1, dmid, din, din_act, G_("norm1.weight"), G_("norm1.bias"),
                         below_bias, M, D)
-        return (ev_last,)
+        if not tr and on_block_done is not None:
+            on_block_done(i)
+        return (ev_last,) if ev_last is not None else None
 
     @staticmethod
     def join_deferred(ws: StackWorkspace) -> None:

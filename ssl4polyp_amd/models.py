@@ -127,17 +127,6 @@ class _Runtime:
                 st.wait_event(ev)
             del self.pending_updates[:last + 1]
 
-    def cls_rows(self, B: int, N: int, dev):
-        """(rows, inv) of BlockStack.backward(sparse_top=...): the cls-token row of every sample among the B * N token rows."""
-        key = ("cls_rows", B, N)
-        hit = self._wcache.get(key)
-        if hit is None:
-            rows = (torch.arange(B, dtype=torch.int32) * N)
-            inv = torch.full((B * N,), -1, dtype=torch.int32)
-            inv[rows.long()] = torch.arange(B, dtype=torch.int32)
-            hit = self._wcache[key] = (rows.to(dev), inv.to(dev))
-        return hit
-
     def block_end(self, prefix: str, i: int) -> int:
         """End offset (in `mat`) of block i's matrices: what `wait_updates` needs before the block runs."""
         f = self.flat
@@ -297,7 +286,12 @@ class _VitClsFn(torch.autograd.Function):
         front_needs = any(need_map.get(n, False) for n in ("cls_token", "pos_embed", "patch_embed.proj.weight", "patch_embed.proj.bias"))
         keep_from = 0 if front_needs else min((i for i in range(g.depth)
                                                 if any(need_map.get(f"blocks.{i}.{n}", False) for n in BLOCK_PARAM_NAMES)), default=g.depth)
-        x = BlockStack(k, g).forward(ws, x0, W, before_block=_update_gate(rt, "blocks."), keep_from=keep_from)
+        # out_token "cls" (models.py:134-136): the head reads row 0 of every sample -- behind its attention the top block runs on those
+        # rows only, forward and backward (engine.BlockStack._top_block_forward_cls / _top_block_sparse).  Training needs B % 8 == 0
+        # (16-byte rows of the k-major weight-gradient operands); otherwise the dense block.
+        cls_top = pool == 0 and k.SPARSE_TOP and N > 1 and (B % 8 == 0 or not any(needs))
+        x = BlockStack(k, g).forward(ws, x0, W, before_block=_update_gate(rt, "blocks."), keep_from=keep_from, cls_top=cls_top)
+        Nh = 1 if cls_top else N   # rows per sample of what the head kernels see
         rt.wait_updates()  # norm / lin_head and anything else still pending
         dev = imgs.device
         f32 = torch.float32
@@ -307,7 +301,7 @@ class _VitClsFn(torch.autograd.Function):
         mean = torch.empty(B * (N if pool else 1), dtype=f32, device=dev)
         rstd = torch.empty_like(mean)
         logits = torch.empty(B, n_class, dtype=f32, device=dev) if head else None
-        _lib.check(k.lib.pm_vit_head_fwd(_ptr(x), N, pool, _ptr(f.param_view("norm.weight")), _ptr(f.param_view("norm.bias")),
+        _lib.check(k.lib.pm_vit_head_fwd(_ptr(x), Nh, pool, _ptr(f.param_view("norm.weight")), _ptr(f.param_view("norm.bias")),
                                          _ptr(f.param_view("lin_head.weight")) if head else None,
                                          _ptr(f.param_view("lin_head.bias")) if head else None, _ptr(feat), _ptr(xhm),
                                          _ptr(mean), _ptr(rstd), _ptr(logits), B, D, n_class, rt.eps, _stream()),
@@ -315,12 +309,13 @@ class _VitClsFn(torch.autograd.Function):
         if training:
             ctx.rt, ctx.names, ctx.ws = rt, names, ws
             if not below:  # the head's backward reads only the last block's output rows: keep those, release the rest
-                x = x.clone() if pool else x.view(B, N, D)[:, 0].clone()
+                x = x.clone() if pool else x.view(B, Nh, D)[:, 0].clone()
                 rt.put_ws(g, ws)
                 ctx.ws = None
                 cols = x0 = None
             ctx.saved = (cols, x0, x, feat, xhm, mean, rstd)
             ctx.dims = (B, L, N, D, n_class, pool, head, below)
+            ctx.cls_top = cls_top
         else:
             rt.put_ws(g, ws)
         return logits if head else feat
@@ -346,9 +341,14 @@ class _VitClsFn(torch.autograd.Function):
             (learn_pos and need("pos_embed"))
         below_head = front or any(trainable)
         dout = dout.contiguous().float()
-        dx = ws.dx[0] if below_head else None
-        dx_act = ws.dx_act[0] if below_head else None
-        x_rows = N if (below or pool) else 1   # linear probe, cls token: only the saved cls rows [B, 1, D]
+        cls_top = bool(getattr(ctx, "cls_top", False))
+        if below_head and cls_top:   # the head's gradient on the B cls rows only ([B, 1, D]): what the cls-row top block takes
+            tc = BlockStack.top_compact(ws, g, k.act_dtype, dout.device)
+            dx, dx_act = tc["dx"], tc["dx_act"]
+        else:
+            dx = ws.dx[0] if below_head else None
+            dx_act = ws.dx_act[0] if below_head else None
+        x_rows = 1 if cls_top else (N if (below or pool) else 1)   # linear probe, cls token: only the saved cls rows [B, 1, D]
         _lib.check(k.lib.pm_vit_head_bwd(
             _ptr(dout) if head else None, None if head else _ptr(dout), _ptr(x), x_rows, pool,
             _ptr(f.param_view("norm.weight")), _ptr(f.param_view("lin_head.weight")) if head else None, _ptr(feat), _ptr(xhm),
@@ -364,12 +364,9 @@ class _VitClsFn(torch.autograd.Function):
             # the incoming dx lives in ws.dx[0]; an odd-depth stack would start writing ws.dx[1] first: fine either way
             # the embedding's backward does not read the blocks' weight gradients: it runs BEFORE the main stream joins the
             # side stream, beside the tail block's last weight-gradient launches instead of behind them
-            # out_token "cls" (models.py:134-136): the head's backward left a gradient in row 0 of every sample and zeros elsewhere
-            sparse = None
-            if pool == 0 and k.SPARSE_TOP and trainable[g.depth - 1]:
-                sparse = rt.cls_rows(B, N, dev=dout.device)
             dx0, _ = BlockStack(k, g).backward(ws, x0, W, G, dx, dx_act, False, trainable, front,
-                                               lambda n, i: accumulate, cb, defer_join=k.DEFER_JOIN, sparse_top=sparse)
+                                               lambda n, i: accumulate, cb, defer_join=k.DEFER_JOIN,
+                                               sparse_top=True if cls_top else None)
             if front and dx0 is not None:
                 _EncoderFrontMixin.front_bwd(rt, dx0, cols, None, B, L, accumulate, need, learn_pos)
             BlockStack.join_deferred(ws)
