@@ -517,11 +517,11 @@ class BlockStack:
         if tc is None:
             B, N, D, Hd, f32 = ws.B, ws.N, g.dim, g.hidden, torch.float32
             e = lambda *s, dt=act_dtype: torch.empty(*s, dtype=dt, device=dev)
-            rows = (torch.arange(B, dtype=torch.int32) * N).to(dev)
-            inv = torch.full((B * N,), -1, dtype=torch.int32)
-            inv[(torch.arange(B) * N)] = torch.arange(B, dtype=torch.int32)
+            rows = torch.arange(B, dtype=torch.int32, device=dev) * N          # (built on the device: no host copy, no sync)
+            inv = torch.full((B * N,), -1, dtype=torch.int32, device=dev)
+            inv[rows.long()] = torch.arange(B, dtype=torch.int32, device=dev)
             tc = ws.__dict__["_top_c"] = dict(
-                rows=rows, inv=inv.to(dev), x=e(B, D, dt=f32), attn=e(B, D), x_mid=e(B, D, dt=f32), ln2=e(B, D), mean2=e(B, dt=f32),
+                rows=rows, inv=inv, x=e(B, D, dt=f32), attn=e(B, D), x_mid=e(B, D, dt=f32), ln2=e(B, D), mean2=e(B, dt=f32),
                 rstd2=e(B, dt=f32), h_pre=e(B, Hd), h_act=e(B, Hd), x_out=e(B, D, dt=f32), dx=e(B, D, dt=f32), dx_act=e(B, D))
         return tc
 

@@ -271,7 +271,7 @@ class _VitClsFn(torch.autograd.Function):
         L = mod.patch_embed.num_patches
         N = L + 1
         D = g.dim
-        needs = ctx.needs_input_grad[5:]
+        needs = ctx.needs_input_grad[5:] if getattr(rt, "grad_enabled", True) else (False,) * len(params)   # (set by ops._vit_forward)
         # (grad mode is already off inside Function.forward.)  Linear probe (finetune.py mode "none": only lin_head
         # trains): nothing below the head needs saved activations -> the forward-only workspace (2 blocks instead of 12).
         below = any(nd for n, nd in zip(names, needs) if not n.startswith("lin_head"))
@@ -446,7 +446,7 @@ class _MaeFn(torch.autograd.Function):
         De, Dd, PE = ge.dim, gd.dim, p * p * C
         dev = imgs.device
         f32 = torch.float32
-        training = any(ctx.needs_input_grad)  # (grad mode is already off inside Function.forward)
+        training = any(ctx.needs_input_grad) and getattr(rt, "grad_enabled", True)  # (grad mode is already off inside Function.forward)
         imgs = imgs.contiguous().float()
         ctx.set_materialize_grads(False)
         # -- masking (models_mae.py:123-148)

@@ -66,12 +66,16 @@ _DEF.define("supervised_loss(Tensor logits, Tensor targets, Tensor? pos_weight, 
 def _vit_forward(imgs, runtime, pool, head, params):
     from .models import _VitClsFn
     rt = _rt(runtime)
+    # grad mode is switched off inside Function.forward, and ctx.needs_input_grad follows the parameters' requires_grad flags whatever
+    # the caller's mode: an evaluation pass under torch.no_grad() over a model with trainable blocks must still take the forward-only path
+    rt.grad_enabled = torch.is_grad_enabled()
     return _VitClsFn.apply(rt, imgs, pool, head, rt.flat.names, *params)
 
 
 def _mae_forward(imgs, noise, mask_ratio, runtime, params):
     from .models import _MaeFn
     rt = _rt(runtime)
+    rt.grad_enabled = torch.is_grad_enabled()
     return _MaeFn.apply(rt, imgs, noise, float(mask_ratio), rt.flat.names, *params)
 
 
